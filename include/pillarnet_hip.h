@@ -1,0 +1,92 @@
+/*
+ * pillarnet_hip.h -- C ABI of the MI355X (gfx950) pillar-detection hot path.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream
+ * (hipStream_t passed as void*).  Nothing here allocates, frees or
+ * synchronises: workspaces are caller-owned, counts that are only known on
+ * the device (number of non-empty pillars, number of kept boxes ...) stay on
+ * the device in caller-provided int32 slots, so a whole frame can be queued
+ * (or captured into a hipGraph) without a host round trip.
+ *
+ * Return value: 0 on success, otherwise a negative PN_E* code or a positive
+ * hipError_t; pn_last_error() returns a thread-local description.  (The
+ * reference's launchers call exit(-1) on a launch error instead:
+ * det3d/ops/pillar_ops/src/pillar_ops_gpu.cu:53-57.)
+ *
+ * Each function cites the reference interface it replaces (paths relative to
+ * the reference root).
+ */
+#ifndef PILLARNET_HIP_H_
+#define PILLARNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_OK 0
+#define PN_EINVAL (-1)   /* bad argument (shape / alignment / capacity)   */
+#define PN_ENOSPC (-2)   /* workspace too small                            */
+#define PN_MAX_BATCH 32  /* batch offsets travel as a kernel argument      */
+
+typedef void* pnStream;  /* hipStream_t */
+
+int pn_abi_version(void);
+const char* pn_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * (a1-a4) point cloud -> pillars, fused.
+ *
+ * Replaces, in one call:
+ *   DynamicPFE.forward                det3d/models/readers/dynamic_pillar_encoder.py:29-50
+ *   PillarQueryAndGroup.forward       det3d/ops/pillar_ops/pillar_utils.py:22-58
+ *     pillar_cuda.create_point_pillar_index_stack_wrapper   src/pillar_ops_gpu.cu:13-58
+ *     pillar_cuda.create_pillar_indices_wrapper              src/pillar_ops_gpu.cu:60-94
+ *     pillar_cuda.gather_indice_wrapper / gather_feature_wrapper  src/group_ops_gpu.cu:8-78
+ *   PillarMaxPooling.forward (eval)   det3d/ops/pillar_ops/pillar_modules.py:56-74
+ *     Linear(F+2 -> C, no bias) + BatchNorm1d(eval) + ReLU, then
+ *     pillar_cuda.scatter_max_wrapper                        src/scatter_ops_gpu.cu:13-60
+ * ------------------------------------------------------------------------ */
+
+typedef struct {
+  int32_t batch;           /* B, 1..PN_MAX_BATCH                              */
+  int32_t height, width;   /* BEV grid (pillar_utils.py:7-10)                 */
+  int32_t point_feats;     /* F: floats per point row (5 nuScenes, 5 Waymo)   */
+  int32_t out_channels;    /* C: PFN width, must be 32                        */
+  float x_min, y_min;      /* pc_range[0], pc_range[1] as fp32                */
+  float inv_pillar;        /* fp32(1) / fp32(pillar_size): torch's device div-by-scalar path */
+  float pillar_size;       /* fp32(pillar_size)                               */
+  float x_offset, y_offset;/* fp32(pillar_size/2 + pc_range[0|1]), computed in double */
+  int32_t true_divide;     /* 1: floor((x-min)/ps) (torch-CPU semantics) instead of *inv */
+} pnPillarGrid;
+
+/* bytes of scratch pn_pillarize needs for `n_points` points on this grid. */
+size_t pn_pillarize_workspace_bytes(const pnPillarGrid* g, int64_t n_points);
+
+/*
+ * points        [n_points, F] fp32, samples concatenated; sample b owns rows
+ *               [batch_offsets[b], batch_offsets[b+1])  (host array, B+1 ints)
+ * pfn_weight    [C, F+2] fp32  (Linear.weight, pillar_modules.py:29)
+ * pfn_scale/shift [C] fp32     eval-mode BatchNorm1d folded: y = relu(x.W^T * scale + shift)
+ * Outputs (capacity rows = min(n_points, B*H*W), only the first *num_pillars are written):
+ * pillar_indices    [cap, 3] int32 (b, y, x), ascending flat index b*H*W + y*W + x
+ * pillar_features   [cap, C] fp32  max over the pillar's points, >= 0
+ * point_pillar_index [n_points] int32 or NULL: row of each point's pillar, -1 if out of range
+ * num_pillars       device int32[1]
+ * occupancy_bits / word_rank: device views into the workspace that the sparse
+ *               backbone reuses (returned through *occ_bits, *occ_rank; may be NULL).
+ */
+int pn_pillarize(const pnPillarGrid* g, const float* points, int64_t n_points,
+                 const int32_t* batch_offsets_host, const float* pfn_weight,
+                 const float* pfn_scale, const float* pfn_shift,
+                 int32_t* pillar_indices, float* pillar_features,
+                 int32_t* point_pillar_index, int32_t* num_pillars,
+                 void* workspace, size_t workspace_bytes,
+                 uint64_t** occ_bits, int32_t** occ_rank, pnStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PILLARNET_HIP_H_ */

@@ -1,0 +1,75 @@
+"""ctypes binding of libpillarnet_hip.so (the C ABI in include/pillarnet_hip.h).
+
+There is no CPU fallback: if the library is missing, `lib()` raises, and every
+operator in this package goes through `lib()`.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpillarnet_hip.so")
+
+PN_MAX_BATCH = 32
+
+
+class PillarnetHipError(RuntimeError):
+    pass
+
+
+class pnPillarGrid(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("height", c_int32), ("width", c_int32),
+        ("point_feats", c_int32), ("out_channels", c_int32),
+        ("x_min", c_float), ("y_min", c_float), ("inv_pillar", c_float),
+        ("pillar_size", c_float), ("x_offset", c_float), ("y_offset", c_float),
+        ("true_divide", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/pillarnet_hip.h
+SIGNATURES = {
+    "pn_abi_version": (c_int, []),
+    "pn_last_error": (c_char_p, []),
+    "pn_pillarize_workspace_bytes": (c_size_t, [POINTER(pnPillarGrid), c_int64]),
+    "pn_pillarize": (c_int, [POINTER(pnPillarGrid), c_void_p, c_int64, POINTER(c_int32),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_size_t, POINTER(c_void_p),
+                             POINTER(c_void_p), c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PillarnetHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc, gfx950). This package has no CPU fallback."
+            )
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pn_last_error().decode("utf-8", "replace")
+        raise PillarnetHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,70 @@
+"""Our stand-in for the subset of `spconv.pytorch` (spconv 2.x, third-party, not vendored by the
+reference) that the hot path uses: `SparseConvTensor` here; the conv modules live in
+`sparse_conv.py`.  Call sites being served: det3d/ops/pillar_ops/pillar_modules.py:74,
+det3d/models/backbones/base.py:9-10,139-140, det3d/models/backbones/PillarResNet.py:139,
+det3d/models/necks/rpn.py:196-199.
+
+MI355X-first difference: the number of active sites is a *device* int32 (`num_active`), tensors
+are allocated at a host-known capacity, and the first `num_active` rows are valid.  Nothing on the
+inference path needs the count on the host, so a frame queues without a sync; `.features` /
+`.indices` (the spconv attributes, exact row count) sync lazily only if somebody asks.
+"""
+import torch
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, num_active=None,
+                 occ_bits=None, occ_rank=None, keepalive=None):
+        """features [cap, C], indices [cap, 3] int32 (b, y, x) sorted by flat index.
+        num_active: device int32[1] (None: every row is active, as in spconv)."""
+        self.features_cap = features
+        self.indices_cap = indices
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = int(batch_size)
+        if num_active is None:
+            num_active = torch.tensor([features.shape[0]], dtype=torch.int32, device=features.device)
+        self.num_active = num_active
+        self.occ_bits = occ_bits      # uint64 words viewed as int64 [ceil(B*H*W/64)]
+        self.occ_rank = occ_rank      # int32 [words]
+        self.indice_dict = {}         # indice_key -> rulebook (spconv's cache, base.py indice_key)
+        self._keepalive = keepalive
+        self._n_host = None
+
+    # -- spconv API ---------------------------------------------------------------------------
+    @property
+    def capacity(self):
+        return self.features_cap.shape[0]
+
+    def num_active_host(self):
+        if self._n_host is None:
+            self._n_host = int(self.num_active.item())  # the one sync, only on request
+        return self._n_host
+
+    @property
+    def features(self):
+        return self.features_cap[: self.num_active_host()]
+
+    @property
+    def indices(self):
+        return self.indices_cap[: self.num_active_host()]
+
+    def replace_feature(self, new_features):
+        """spconv 2.x `replace_feature` (used at base.py:9-10): same sites, new feature rows."""
+        if new_features.shape[0] != self.capacity:
+            assert new_features.shape[0] == self.num_active_host()
+            full = self.features_cap.new_empty((self.capacity, new_features.shape[1]),
+                                               dtype=new_features.dtype)
+            full[: new_features.shape[0]] = new_features
+            new_features = full
+        out = SparseConvTensor(new_features, self.indices_cap, self.spatial_shape, self.batch_size,
+                               self.num_active, self.occ_bits, self.occ_rank, self._keepalive)
+        out.indice_dict = self.indice_dict
+        out._n_host = self._n_host
+        return out
+
+    def dense(self, channels_last=True):
+        """[B, C, H, W]; zero where inactive (spconv `.dense()`, PillarResNet.py:139).  The memory
+        format is channels-last (each active row lands as one contiguous C-vector, and the MIOpen
+        convs downstream want NHWC)."""
+        from . import sparse_conv
+        return sparse_conv.to_dense(self, channels_last=channels_last)
