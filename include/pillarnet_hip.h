@@ -86,6 +86,36 @@ int pn_pillarize(const pnPillarGrid* g, const float* points, int64_t n_points,
                  void* workspace, size_t workspace_bytes,
                  uint64_t** occ_bits, int32_t** occ_rank, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * (a10/a11) rotated-BEV NMS with on-device greedy selection, batched over
+ * independent box sets (one per task x sample).
+ *
+ * Replaces iou3d_nms_cuda.nms_gpu  (det3d/ops/iou3d_nms/src/iou3d_nms_api.cpp:15,
+ * iou3d_nms.cpp:113-159, nms_kernel iou3d_nms_kernel.cu:280-324) and the
+ * `[:post_max_size]` slice of rotate_nms_pcdet (det3d/core/bbox/box_torch_ops.py:315-317).
+ *
+ * boxes      [num_sets, cap, 7] fp32, pcdet frame (x,y,z,dx,dy,dz,heading), each set
+ *            sorted by score descending; cap <= 4096
+ * counts_dev device int32[num_sets] valid boxes per set (clamped to cap), or NULL to
+ *            use the host value count_host for every set
+ * thresh_dev device fp32[num_sets] IoU thresholds or NULL -> `thresh` for all
+ * post_max_dev device int32[num_sets] or NULL -> `post_max` for all
+ * keep       [num_sets, keep_stride] int32: positions (into the sorted set) of the
+ *            kept boxes, ascending; num_keep device int32[num_sets]
+ * ------------------------------------------------------------------------ */
+size_t pn_nms_workspace_bytes(int num_sets, int cap);
+int pn_nms_rotated(const float* boxes, int num_sets, int cap, const int32_t* counts_dev,
+                   int count_host, const float* thresh_dev, float thresh,
+                   const int32_t* post_max_dev, int post_max, int keep_stride,
+                   int32_t* keep, int32_t* num_keep, void* workspace,
+                   size_t workspace_bytes, pnStream stream);
+
+/* iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu / boxes_aligned_overlap_bev_gpu
+ * (iou3d_nms_api.cpp:12-14, kernels iou3d_nms_kernel.cu:236-278).
+ * out is [na, nb] (aligned = 0) or [na] (aligned = 1, na == nb); want_iou = 0 -> overlap area. */
+int pn_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
+                          int aligned, int want_iou, float* out, pnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

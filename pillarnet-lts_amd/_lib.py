@@ -36,6 +36,12 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_size_t, POINTER(c_void_p),
                              POINTER(c_void_p), c_void_p]),
+    "pn_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pn_nms_rotated": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_float,
+                               c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
+    "pn_boxes_pairwise_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                      c_void_p]),
 }
 
 _lib = None

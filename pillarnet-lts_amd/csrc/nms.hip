@@ -1,0 +1,354 @@
+// (a10/a11) rotated-BEV IoU and greedy NMS for gfx950, selection included, no host round trip.
+//
+// Reference being replaced:
+//   det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:36-234   geometry (box_overlap / iou_bev)
+//   det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:280-324  nms_kernel: 64x64 tile per 64-thread block,
+//                                                        every lane walks 64 column boxes serially
+//   det3d/ops/iou3d_nms/src/iou3d_nms.cpp:113-159        cudaMalloc + blocking D2H of the bit matrix +
+//                                                        serial greedy loop on the host
+//
+// Here:
+//   nms_mask_kernel    one 256-thread workgroup per *upper-triangle* 64x64 tile (the greedy pass
+//                      never reads the lower triangle).  Per-box data (rotated corners, cos/sin,
+//                      bounding radius) is computed once into LDS.  All 4096 pairs get a
+//                      bounding-circle test; survivors are compacted into an LDS list so that the
+//                      expensive polygon clip runs on dense wavefronts instead of one lane in 64.
+//                      A pair that fails the circle test has overlap exactly 0 in the reference
+//                      (no edge crossing, no corner within the 1 cm slack), so the bit matrix is
+//                      unchanged for any threshold >= 0.
+//   nms_select_kernel  one wavefront per box set.  Lane c owns removal word c; the 64 rows of a
+//                      block are resolved with a ctz walk over the still-alive bits (wave-uniform
+//                      readlane of the diagonal word), then the kept rows' later words are OR-ed
+//                      in by lane.  Stops as soon as post_max boxes are kept.
+//
+// -ffp-contract=off: products and sums round separately, as in the reference's CPU twin
+// (iou3d_cpu.cpp) which the oracle is pinned to.
+#include "common.h"
+
+static constexpr float IOU_EPS = 1e-8f;
+static constexpr float IN_BOX_MARGIN = 1e-2f;
+static constexpr int MAX_POLY = 24;
+
+struct pt2 {
+  float x, y;
+};
+
+// everything box_overlap needs about one box, computed once
+struct BoxGeom {
+  pt2 c[4];            // rotated corners
+  float cx, cy;        // centre
+  float cneg, sneg;    // cos(-heading), sin(-heading)
+  float hx_m, hy_m;    // dx/2 + margin, dy/2 + margin
+  float area;          // dx*dy
+  float radius;        // half diagonal (+ slack) for the circle pre-test
+};
+
+__device__ __forceinline__ float cross3(pt2 p1, pt2 p2, pt2 p0) {
+  return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+__device__ __forceinline__ pt2 rotate_about(float cx, float cy, float c, float s, float px, float py) {
+  pt2 r;
+  r.x = (px - cx) * c + (py - cy) * (-s) + cx;
+  r.y = (px - cx) * s + (py - cy) * c + cy;
+  return r;
+}
+
+__device__ __forceinline__ void make_geom(const float* __restrict__ b, BoxGeom& g) {
+  const float hx = b[3] / 2, hy = b[4] / 2;
+  const float x1 = b[0] - hx, y1 = b[1] - hy, x2 = b[0] + hx, y2 = b[1] + hy;
+  const float c = cosf(b[6]), s = sinf(b[6]);
+  g.cx = b[0];
+  g.cy = b[1];
+  g.c[0] = rotate_about(b[0], b[1], c, s, x1, y1);
+  g.c[1] = rotate_about(b[0], b[1], c, s, x2, y1);
+  g.c[2] = rotate_about(b[0], b[1], c, s, x2, y2);
+  g.c[3] = rotate_about(b[0], b[1], c, s, x1, y2);
+  g.cneg = cosf(-b[6]);
+  g.sneg = sinf(-b[6]);
+  g.hx_m = hx + IN_BOX_MARGIN;
+  g.hy_m = hy + IN_BOX_MARGIN;
+  g.area = b[3] * b[4];
+  g.radius = sqrtf(hx * hx + hy * hy) * 1.0001f + 0.02f;
+}
+
+__device__ __forceinline__ bool seg_intersection(pt2 p1, pt2 p0, pt2 q1, pt2 q0, pt2& out) {
+  // iou3d_nms_kernel.cu:63-92
+  const bool bb = fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+                  fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y);
+  if (!bb) return false;
+  const float s1 = cross3(q0, p1, p0);
+  const float s2 = cross3(p1, q1, p0);
+  const float s3 = cross3(p0, q1, q0);
+  const float s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+  const float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > IOU_EPS) {
+    out.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    out.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    const float D = a0 * b1 - a1 * b0;
+    out.x = (b0 * c1 - b1 * c0) / D;
+    out.y = (a1 * c0 - a0 * c1) / D;
+  }
+  return true;
+}
+
+__device__ __forceinline__ bool point_in_box(const BoxGeom& g, pt2 p) {
+  // iou3d_nms_kernel.cu:51-61
+  const float rx = (p.x - g.cx) * g.cneg + (p.y - g.cy) * (-g.sneg);
+  const float ry = (p.x - g.cx) * g.sneg + (p.y - g.cy) * g.cneg;
+  return fabsf(rx) < g.hx_m && fabsf(ry) < g.hy_m;
+}
+
+__device__ float box_overlap(const BoxGeom& A, const BoxGeom& B) {
+  // iou3d_nms_kernel.cu:104-225
+  pt2 poly[MAX_POLY];
+  float ang[MAX_POLY];
+  float sx = 0.f, sy = 0.f;
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pt2 x;
+      if (seg_intersection(A.c[(i + 1) & 3], A.c[i], B.c[(j + 1) & 3], B.c[j], x)) {
+        sx = sx + x.x;
+        sy = sy + x.y;
+        poly[cnt++] = x;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (point_in_box(A, B.c[k])) {
+      sx = sx + B.c[k].x; sy = sy + B.c[k].y;
+      poly[cnt++] = B.c[k];
+    }
+    if (point_in_box(B, A.c[k])) {
+      sx = sx + A.c[k].x; sy = sy + A.c[k].y;
+      poly[cnt++] = A.c[k];
+    }
+  }
+  if (cnt < 3) return 0.f;  // reference: the area loop adds nothing meaningful (0, or one zero cross)
+  const float mx = sx / cnt, my = sy / cnt;
+  for (int k = 0; k < cnt; ++k) ang[k] = atan2f(poly[k].y - my, poly[k].x - mx);
+  // same bubble sort as the reference (stable, strict >); angles are evaluated once per vertex
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (ang[i] > ang[i + 1]) {
+        const pt2 t = poly[i]; poly[i] = poly[i + 1]; poly[i + 1] = t;
+        const float u = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = u;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    const float ux = poly[k].x - poly[0].x, uy = poly[k].y - poly[0].y;
+    const float vx = poly[k + 1].x - poly[0].x, vy = poly[k + 1].y - poly[0].y;
+    area += ux * vy - uy * vx;
+  }
+  return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_from_overlap(const BoxGeom& A, const BoxGeom& B, float ov) {
+  return ov / fmaxf(A.area + B.area - ov, IOU_EPS);
+}
+
+__device__ __forceinline__ bool circles_apart(const BoxGeom& A, const BoxGeom& B) {
+  const float dx = A.cx - B.cx, dy = A.cy - B.cy;
+  const float r = A.radius + B.radius;
+  return dx * dx + dy * dy > r * r;  // false for NaN: falls through to the exact path
+}
+
+// ------------------------------------------------------------------------------------------------
+static constexpr int NMS_TILE = 64;
+static constexpr int NMS_THREADS = 256;
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_mask_kernel(
+    const float* __restrict__ boxes, const int32_t* __restrict__ counts, int count_is_host_n,
+    int cap, int col_blocks, int tiles_per_set, const float* __restrict__ thresh_per_set,
+    float thresh_all, unsigned long long* __restrict__ mask) {
+  __shared__ BoxGeom rowg[NMS_TILE];
+  __shared__ BoxGeom colg[NMS_TILE];
+  __shared__ unsigned long long lmask[NMS_TILE];
+  __shared__ unsigned short plist[NMS_TILE * NMS_TILE];
+  __shared__ int pcount;
+
+  const int set = blockIdx.x / tiles_per_set;
+  int tile = blockIdx.x - set * tiles_per_set;
+  // unrank the upper-triangle tile: rows rb, columns cb >= rb
+  int rb = 0, rem = col_blocks;
+  while (tile >= rem) { tile -= rem; ++rb; --rem; }
+  const int cb = rb + tile;
+
+  int n = count_is_host_n ? count_is_host_n : counts[set];
+  if (n > cap) n = cap;
+  if (rb * NMS_TILE >= n || cb * NMS_TILE >= n) return;
+  const float thr = thresh_per_set ? thresh_per_set[set] : thresh_all;
+  const float* B = boxes + (size_t)set * cap * 7;
+  const int tid = threadIdx.x;
+
+  if (tid < NMS_TILE) {
+    const int r = rb * NMS_TILE + tid;
+    if (r < n) make_geom(B + (size_t)r * 7, rowg[tid]);
+    lmask[tid] = 0ull;
+  } else if (tid < 2 * NMS_TILE) {
+    const int c = cb * NMS_TILE + (tid - NMS_TILE);
+    if (c < n) make_geom(B + (size_t)c * 7, colg[tid - NMS_TILE]);
+  }
+  if (tid == 0) pcount = 0;
+  __syncthreads();
+
+  {
+    const int r = tid & 63, c0 = (tid >> 6) * 16;
+    const int gr = rb * NMS_TILE + r;
+    if (gr < n) {
+      for (int k = 0; k < 16; ++k) {
+        const int c = c0 + k, gc = cb * NMS_TILE + c;
+        if (gc < n && gc > gr && !(thr >= 0.f && circles_apart(rowg[r], colg[c]))) {
+          const int pos = atomicAdd(&pcount, 1);
+          plist[pos] = (unsigned short)((r << 6) | c);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int np = pcount;
+  for (int p = tid; p < np; p += NMS_THREADS) {
+    const int r = plist[p] >> 6, c = plist[p] & 63;
+    const float ov = box_overlap(rowg[r], colg[c]);
+    if (iou_from_overlap(rowg[r], colg[c], ov) > thr) atomicOr(&lmask[r], 1ull << c);
+  }
+  __syncthreads();
+  if (tid < NMS_TILE) {
+    const int r = rb * NMS_TILE + tid;
+    if (r < n)
+      mask[((size_t)set * cap + r) * col_blocks + cb] = lmask[tid];
+  }
+}
+
+__global__ __launch_bounds__(64) void nms_select_kernel(
+    const unsigned long long* __restrict__ mask, const int32_t* __restrict__ counts,
+    int count_is_host_n, int cap, int col_blocks, const int32_t* __restrict__ post_max_per_set,
+    int post_max_all, int keep_stride, int32_t* __restrict__ keep, int32_t* __restrict__ num_keep) {
+  const int set = blockIdx.x, lane = threadIdx.x;
+  int n = count_is_host_n ? count_is_host_n : counts[set];
+  if (n > cap) n = cap;
+  if (n < 0) n = 0;
+  int post_max = post_max_per_set ? post_max_per_set[set] : post_max_all;
+  if (post_max > keep_stride) post_max = keep_stride;
+  const int nb = (n + 63) >> 6;
+  const unsigned long long* M = mask + (size_t)set * cap * col_blocks;
+  int32_t* K = keep + (size_t)set * keep_stride;
+
+  unsigned long long remv = 0ull;  // lane c: removal bits of block c
+  int kept_total = 0;
+  for (int b = 0; b < nb && kept_total < post_max; ++b) {
+    const int row = b * 64 + lane;
+    const unsigned long long diag = row < n ? M[(size_t)row * col_blocks + b] : 0ull;
+    unsigned long long removed = __shfl(remv, b);
+    const int rows_here = n - b * 64;
+    if (rows_here < 64) removed |= ~0ull << rows_here;
+    unsigned long long kept = 0ull, alive = ~removed;
+    while (alive) {  // wave-uniform
+      const int j = __builtin_ctzll(alive);
+      kept |= 1ull << j;
+      removed |= __shfl(diag, j);
+      alive = j == 63 ? 0ull : (~removed & (~0ull << (j + 1)));
+    }
+    if ((kept >> lane) & 1ull) {
+      const int pos = kept_total + __popcll(kept & ((1ull << lane) - 1ull));
+      if (pos < post_max) K[pos] = row;
+    }
+    kept_total += __popcll(kept);
+    if (lane > b && lane < nb) {
+      unsigned long long km = kept, acc = 0ull;
+      while (km) {
+        const int j = __builtin_ctzll(km);
+        km &= km - 1ull;
+        acc |= M[(size_t)(b * 64 + j) * col_blocks + lane];
+      }
+      remv |= acc;
+    }
+  }
+  if (lane == 0) num_keep[set] = kept_total < post_max ? kept_total : post_max;
+}
+
+// all-pairs / aligned overlap or IoU (boxes_overlap_kernel, boxes_iou_bev_kernel,
+// boxes_aligned_overlap_kernel: iou3d_nms_kernel.cu:236-278)
+__global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__ a, int na,
+                                                       const float* __restrict__ b, int nb,
+                                                       int aligned, int want_iou,
+                                                       float* __restrict__ out) {
+  const long long total = aligned ? na : (long long)na * nb;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int i = aligned ? (int)t : (int)(t / nb);
+    const int j = aligned ? (int)t : (int)(t - (long long)i * nb);
+    BoxGeom A, Bg;
+    make_geom(a + (size_t)i * 7, A);
+    make_geom(b + (size_t)j * 7, Bg);
+    float v = circles_apart(A, Bg) ? 0.f : box_overlap(A, Bg);
+    if (want_iou) v = iou_from_overlap(A, Bg, v);
+    out[t] = v;
+  }
+}
+
+extern "C" size_t pn_nms_workspace_bytes(int num_sets, int cap) {
+  if (num_sets <= 0 || cap <= 0) return 0;
+  const size_t cbk = (size_t)(cap + 63) / 64;
+  return pn_align_up((size_t)num_sets * cap * cbk * 8, 256);
+}
+
+extern "C" int pn_nms_rotated(const float* boxes, int num_sets, int cap, const int32_t* counts_dev,
+                              int count_host, const float* thresh_dev, float thresh,
+                              const int32_t* post_max_dev, int post_max, int keep_stride,
+                              int32_t* keep, int32_t* num_keep, void* workspace,
+                              size_t workspace_bytes, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(num_sets >= 1 && cap >= 1 && cap <= 4096, "pn_nms_rotated: sets %d cap %d (cap <= 4096)",
+               num_sets, cap);
+  PN_CHECK_ARG(boxes && keep && num_keep && workspace, "pn_nms_rotated: null argument");
+  PN_CHECK_ARG(counts_dev || (count_host >= 1 && count_host <= cap),
+               "pn_nms_rotated: need device counts or a host count in 1..cap (got %d)", count_host);
+  PN_CHECK_ARG(keep_stride >= 1 && (post_max_dev || post_max >= 1), "pn_nms_rotated: bad post_max");
+  if (workspace_bytes < pn_nms_workspace_bytes(num_sets, cap)) {
+    pn_set_error("pn_nms_rotated: workspace %zu < %zu bytes", workspace_bytes,
+                 pn_nms_workspace_bytes(num_sets, cap));
+    return PN_ENOSPC;
+  }
+  const int n_for_grid = counts_dev ? cap : count_host;
+  const int cbk_store = (cap + 63) / 64;
+  const int cbk_grid = (n_for_grid + 63) / 64;
+  // tile unranking walks the triangle of the *stored* width, so launch that triangle's tiles
+  // whose rows/cols can be populated; tiles past n return immediately
+  (void)cbk_grid;
+  const int tiles = cbk_store * (cbk_store + 1) / 2;
+  unsigned long long* mask = (unsigned long long*)workspace;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(tiles * num_sets), dim3(NMS_THREADS), 0, stream, boxes,
+                     counts_dev, counts_dev ? 0 : count_host, cap, cbk_store, tiles, thresh_dev,
+                     thresh, mask);
+  PN_CHECK_LAUNCH("nms_mask_kernel");
+  hipLaunchKernelGGL(nms_select_kernel, dim3(num_sets), dim3(64), 0, stream, mask, counts_dev,
+                     counts_dev ? 0 : count_host, cap, cbk_store, post_max_dev, post_max,
+                     keep_stride, keep, num_keep);
+  PN_CHECK_LAUNCH("nms_select_kernel");
+  return PN_OK;
+}
+
+extern "C" int pn_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
+                                     int aligned, int want_iou, float* out, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(na >= 0 && nb >= 0 && out, "pn_boxes_pairwise_bev: bad argument");
+  PN_CHECK_ARG(!aligned || na == nb, "pn_boxes_pairwise_bev: aligned needs na == nb");
+  const long long total = aligned ? na : (long long)na * nb;
+  if (total == 0) return PN_OK;
+  PN_CHECK_ARG(boxes_a && boxes_b, "pn_boxes_pairwise_bev: null boxes");
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pairwise_kernel, dim3((int)blocks), dim3(256), 0, stream, boxes_a, na, boxes_b,
+                     nb, aligned, want_iou, out);
+  PN_CHECK_LAUNCH("pairwise_kernel");
+  return PN_OK;
+}
