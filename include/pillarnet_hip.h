@@ -30,6 +30,8 @@ extern "C" {
 #define PN_EINVAL (-1)   /* bad argument (shape / alignment / capacity)   */
 #define PN_ENOSPC (-2)   /* workspace too small                            */
 #define PN_MAX_BATCH 32  /* batch offsets travel as a kernel argument      */
+#define PN_DTYPE_F32 0   /* feature / weight element type of the sparse ops */
+#define PN_DTYPE_BF16 1
 
 typedef void* pnStream;  /* hipStream_t */
 
@@ -115,6 +117,60 @@ int pn_nms_rotated(const float* boxes, int num_sets, int cap, const int32_t* cou
  * out is [na, nb] (aligned = 0) or [na] (aligned = 1, na == nb); want_iou = 0 -> overlap area. */
 int pn_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
                           int aligned, int want_iou, float* out, pnStream stream);
+
+/* ------------------------------------------------------------------------
+ * (a5/a6) 2-D sparse convolution on the bit/rank occupancy index.
+ *
+ * Stands in for spconv 2.x (third-party, not vendored by the reference) as used by
+ * det3d/models/backbones/base.py:38-63 (conv2D3x3 -> SubMConv2d / SparseConv2d) and
+ * det3d/models/backbones/PillarResNet.py:81-108,139 (SparseConv2d(3, 2, padding=1), .dense()).
+ * Rows of every sparse tensor are sorted by flat index b*H*W + y*W + x; the active-row count
+ * lives in device memory.
+ * ------------------------------------------------------------------------ */
+
+/* Rulebook of a 3x3 submanifold conv (stride 1, pad 1, dilation 1): nbr[k*cap + m] = row of the
+ * active cell at offset k = ky*3+kx (dy = ky-1, dx = kx-1) from row m, or -1.  Shared by every
+ * conv with the same indice_key. */
+int pn_spconv_subm_rules(const int32_t* indices, const int32_t* count_dev, int cap,
+                         int batch, int H, int W, const uint64_t* occ_bits,
+                         const int32_t* occ_rank, int32_t* nbr, pnStream stream);
+
+/* Active set + rulebook of a 3x3 / stride s / pad p sparse conv: builds the output level's
+ * occupancy (out_bits, out_rank), sorted (b,y,x) rows, count, and nbr[k*out_cap + o] = input
+ * row at window position k of output row o, or -1. */
+size_t pn_spconv_down_scratch_bytes(int batch, int Ho, int Wo);
+int pn_spconv_down_rules(const int32_t* in_indices, const int32_t* in_count_dev,
+                         int in_cap, int batch, int H, int W, const uint64_t* in_bits,
+                         const int32_t* in_rank, int stride, int pad, int Ho, int Wo,
+                         int32_t* out_indices, int32_t* out_count_dev, int out_cap,
+                         uint64_t* out_bits, int32_t* out_rank, int32_t* nbr,
+                         void* scratch, size_t scratch_bytes, pnStream stream);
+
+/* out[m, :] = act( (sum_k W[k] . in[nbr[k][m], :]) * scale + shift (+ residual[m, :]) )
+ * in [*, cin], out/residual [cap, cout] of `dtype`; weight [9, cout, cin] of `dtype`
+ * (spconv 2.x stores [cout, 3, 3, cin]); scale/shift fp32 [cout] (conv bias and eval-mode
+ * BatchNorm1d folded; base.py:154-170); relu != 0 applies max(.,0).  fp32 accumulation. */
+int pn_spconv_forward(int dtype, const void* in, int cin, const int32_t* nbr,
+                      int nbr_stride, const int32_t* count_dev, int cap,
+                      const void* weight, const float* scale, const float* shift,
+                      const void* residual, int relu, void* out, int cout, pnStream stream);
+
+/* SparseConvTensor.dense(): zero-fills out and writes the active rows;
+ * channels_last != 0 -> [B,H,W,C] memory, else [B,C,H,W]. */
+int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* indices,
+                       const int32_t* count_dev, int cap, int batch, int H, int W, int C,
+                       int channels_last, void* out, pnStream stream);
+
+/* Occupancy index (bit per cell + per-word rank) of an existing sparse tensor's (b,y,x) rows --
+ * what `spconv.SparseConvTensor(features, indices, spatial_shape, batch)`
+ * (det3d/ops/pillar_ops/pillar_modules.py:74) needs before the first conv.  Rows must be in
+ * ascending flat-index order; *active_cells_dev receives the number of distinct cells (equals the
+ * row count iff there are no duplicates). */
+size_t pn_occupancy_scratch_bytes(int batch, int H, int W);
+int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, int cap,
+                              int batch, int H, int W, uint64_t* occ_bits,
+                              int32_t* occ_rank, int32_t* active_cells_dev,
+                              void* scratch, size_t scratch_bytes, pnStream stream);
 
 #ifdef __cplusplus
 }

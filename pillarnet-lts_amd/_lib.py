@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpillarnet_hip.so")
 
 PN_MAX_BATCH = 32
+PN_DTYPE_F32, PN_DTYPE_BF16 = 0, 1
 
 
 class PillarnetHipError(RuntimeError):
@@ -42,6 +43,21 @@ SIGNATURES = {
                                c_void_p]),
     "pn_boxes_pairwise_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                       c_void_p]),
+    "pn_spconv_subm_rules": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "pn_spconv_down_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pn_spconv_down_rules": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
+    "pn_spconv_forward": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p]),
+    "pn_sparse_to_dense": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_void_p]),
+    "pn_occupancy_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pn_occupancy_from_indices": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void occ_rank_emit_kernel(
       const int b = cell / hw;
       const int rem = cell - b * hw;
       const int y = rem / W;
-      if (r < row_cap) {
+      if (indices && r < row_cap) {
         indices[r * 3 + 0] = b;
         indices[r * 3 + 1] = y;
         indices[r * 3 + 2] = rem - y * W;
@@ -131,4 +131,48 @@ int pn_occupancy_scan(const unsigned long long* bits, int64_t cells, int H, int 
                      (uint4*)zero_rows, zero_row_bytes / 16, (long long)row_cap);
   PN_CHECK_LAUNCH("occ_rank_emit_kernel");
   return PN_OK;
+}
+
+// occupancy index of an existing (b,y,x) row list (rows must already be in ascending flat
+// order, which is what every producer in this library emits)
+__global__ __launch_bounds__(SCAN_THREADS) void occ_mark_rows_kernel(
+    const int32_t* __restrict__ indices, const int32_t* __restrict__ count, int cap, int B, int H,
+    int W, unsigned long long* __restrict__ bits) {
+  int M = *count;
+  if (M > cap) M = cap;
+  for (int m = blockIdx.x * SCAN_THREADS + threadIdx.x; m < M; m += gridDim.x * SCAN_THREADS) {
+    const int b = indices[m * 3 + 0], y = indices[m * 3 + 1], x = indices[m * 3 + 2];
+    if (b < 0 || b >= B || y < 0 || y >= H || x < 0 || x >= W) continue;
+    const int cell = (b * H + y) * W + x;
+    atomicOr(&bits[cell >> 6], 1ull << (cell & 63));
+  }
+}
+
+extern "C" size_t pn_occupancy_scratch_bytes(int batch, int H, int W) {
+  const pnScanGeom sg = pn_scan_geom((int64_t)batch * H * W);
+  return pn_align_up((size_t)sg.blocks * 4, 256);
+}
+
+extern "C" int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, int cap,
+                                         int batch, int H, int W, uint64_t* occ_bits,
+                                         int32_t* occ_rank, int32_t* active_cells_dev,
+                                         void* scratch, size_t scratch_bytes, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(indices && count_dev && occ_bits && occ_rank && active_cells_dev && scratch,
+               "pn_occupancy_from_indices: null argument");
+  const int64_t cells = (int64_t)batch * H * W;
+  PN_CHECK_ARG(cap >= 1 && cells > 0 && cells < (1ll << 31), "pn_occupancy_from_indices: bad shape");
+  if (scratch_bytes < pn_occupancy_scratch_bytes(batch, H, W)) {
+    pn_set_error("pn_occupancy_from_indices: scratch too small");
+    return PN_ENOSPC;
+  }
+  const pnScanGeom sg = pn_scan_geom(cells);
+  PN_CHECK_HIP(hipMemsetAsync(occ_bits, 0, (size_t)sg.words * 8, stream));
+  int blocks = pn_div_up(cap, SCAN_THREADS);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(occ_mark_rows_kernel, dim3(blocks), dim3(SCAN_THREADS), 0, stream, indices,
+                     count_dev, cap, batch, H, W, (unsigned long long*)occ_bits);
+  PN_CHECK_LAUNCH("occ_mark_rows_kernel");
+  return pn_occupancy_scan((const unsigned long long*)occ_bits, cells, H, W, occ_rank,
+                           (int32_t*)scratch, nullptr, active_cells_dev, nullptr, 0, cap, stream);
 }

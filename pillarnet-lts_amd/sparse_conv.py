@@ -1,0 +1,247 @@
+"""Sparse-conv modules with the `spconv.pytorch` constructor signatures and state-dict layout the
+reference's backbone uses (det3d/models/backbones/base.py:3-4,38-63, PillarResNet.py:4,81-108):
+`SubMConv2d`, `SparseConv2d`, `SparseSequential`, `SparseReLU`, `SparseModule`.
+
+Weights keep spconv 2.x's KRSC layout `[out, kh, kw, in]` (+ `bias [out]`), so reference
+checkpoints load key-for-key (det3d/torchie/trainer/checkpoint.py:49-64 describes the layouts).
+Compute goes through the HIP C ABI (`pn_spconv_*`); eval-mode `conv -> BatchNorm1d -> ReLU`
+chains inside a `SparseSequential` run as ONE kernel with the norm folded into the epilogue.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .spconv import SparseConvTensor
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return _lib.PN_DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.PN_DTYPE_BF16
+    raise _lib.PillarnetHipError(f"sparse features must be fp32 or bf16, got {t.dtype}")
+
+
+class SparseModule(nn.Module):
+    """marker base class, as in spconv"""
+
+
+class SparseReLU(SparseModule):
+    def forward(self, x):
+        if isinstance(x, SparseConvTensor):
+            return x.replace_feature(torch.relu(x.features_cap))
+        return torch.relu(x)
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, subm=False, indice_key=None):
+        super().__init__()
+        if kernel_size not in (3, (3, 3), [3, 3]) or dilation not in (1, (1, 1), [1, 1]) or groups != 1:
+            raise NotImplementedError("the HIP sparse conv implements 3x3, dilation 1, groups 1")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (3, 3)
+        self.stride = stride if isinstance(stride, int) else stride[0]
+        self.padding = padding if isinstance(padding, int) else padding[0]
+        self.subm = subm
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+        self._packed = {}
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(9 * self.in_channels)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def packed(self, dtype, bn=None):
+        """([9, out, in] weight in `dtype`, fp32 scale, fp32 shift) with the conv bias and an
+        eval-mode norm folded; cached until a parameter or buffer changes."""
+        key = (dtype, self.weight._version, None if self.bias is None else self.bias._version,
+               self.weight.device, id(bn))
+        if bn is not None:
+            key += (bn.weight._version, bn.bias._version, bn.running_mean._version,
+                    bn.running_var._version)
+        hit = self._packed.get(dtype)
+        if hit is not None and hit[0] == key:
+            return hit[1:]
+        with torch.no_grad():
+            w = self.weight.detach().permute(1, 2, 0, 3).reshape(9, self.out_channels, self.in_channels)
+            w = w.to(dtype).contiguous()
+            if bn is not None:
+                from .pillar_ops import fold_batchnorm
+                scale, shift = fold_batchnorm(bn, self.bias)
+            else:
+                scale = torch.ones(self.out_channels, device=w.device)
+                shift = (self.bias.detach().float().clone() if self.bias is not None
+                         else torch.zeros(self.out_channels, device=w.device))
+        self._packed[dtype] = (key, w, scale.contiguous(), shift.contiguous())
+        return w, scale, shift
+
+    def forward(self, x, bn=None, relu=False, residual=None):
+        return conv_forward(x, self, bn, relu, residual)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, True, indice_key)
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, False, indice_key)
+
+
+def _subm_rules(x: SparseConvTensor, key):
+    cached = x.indice_dict.get(key) if key is not None else None
+    if cached is not None:
+        return cached
+    dev = x.features_cap.device
+    cap = x.capacity
+    H, W = x.spatial_shape
+    nbr = torch.empty((9, cap), dtype=torch.int32, device=dev)
+    rc = _lib.lib().pn_spconv_subm_rules(_lib.ptr(x.indices_cap), _lib.ptr(x.num_active), cap,
+                                         x.batch_size, H, W, _lib.ptr(x.occ_bits),
+                                         _lib.ptr(x.occ_rank), _lib.ptr(nbr), _lib.current_stream(dev))
+    _lib.check(rc, "pn_spconv_subm_rules")
+    if key is not None:
+        x.indice_dict[key] = nbr
+    return nbr
+
+
+def _down_rules(x: SparseConvTensor, stride, pad):
+    dev = x.features_cap.device
+    H, W = x.spatial_shape
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    B = x.batch_size
+    out_cap = max(1, min(x.capacity, B * Ho * Wo))
+    words = (B * Ho * Wo + 63) // 64
+    L = _lib.lib()
+    out_idx = torch.empty((out_cap, 3), dtype=torch.int32, device=dev)
+    out_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    out_bits = torch.empty(words, dtype=torch.int64, device=dev)
+    out_rank = torch.empty(words, dtype=torch.int32, device=dev)
+    nbr = torch.empty((9, out_cap), dtype=torch.int32, device=dev)
+    sb = L.pn_spconv_down_scratch_bytes(B, Ho, Wo)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    rc = L.pn_spconv_down_rules(_lib.ptr(x.indices_cap), _lib.ptr(x.num_active), x.capacity, B, H, W,
+                                _lib.ptr(x.occ_bits), _lib.ptr(x.occ_rank), stride, pad, Ho, Wo,
+                                _lib.ptr(out_idx), _lib.ptr(out_num), out_cap, _lib.ptr(out_bits),
+                                _lib.ptr(out_rank), _lib.ptr(nbr), _lib.ptr(scratch), sb,
+                                _lib.current_stream(dev))
+    _lib.check(rc, "pn_spconv_down_rules")
+    return out_idx, out_num, out_bits, out_rank, nbr, (Ho, Wo), out_cap
+
+
+def conv_forward(x: SparseConvTensor, conv: SparseConvolution, bn=None, relu=False, residual=None):
+    """conv (+ folded eval-mode norm) (+ residual rows) (+ ReLU) as one kernel."""
+    feats = x.features_cap
+    if feats.device.type != "cuda":
+        raise _lib.PillarnetHipError("sparse conv: features must live on the GPU (no CPU fallback)")
+    if conv.training or (bn is not None and bn.training):
+        raise NotImplementedError("training-mode sparse conv / BatchNorm is not built yet; call .eval()")
+    dt = _dtype_code(feats)
+    w, scale, shift = conv.packed(feats.dtype, bn)
+    dev = feats.device
+    if conv.subm:
+        assert conv.stride == 1 and conv.padding == 1, "SubMConv2d 3x3 needs stride 1, padding 1"
+        nbr = _subm_rules(x, conv.indice_key)
+        cap, num = x.capacity, x.num_active
+        out = torch.empty((cap, conv.out_channels), dtype=feats.dtype, device=dev)
+        res = residual.features_cap if isinstance(residual, SparseConvTensor) else residual
+        rc = _lib.lib().pn_spconv_forward(dt, _lib.ptr(feats), conv.in_channels, _lib.ptr(nbr), cap,
+                                          _lib.ptr(num), cap, _lib.ptr(w), _lib.ptr(scale),
+                                          _lib.ptr(shift), _lib.ptr(res), int(relu), _lib.ptr(out),
+                                          conv.out_channels, _lib.current_stream(dev))
+        _lib.check(rc, "pn_spconv_forward")
+        return x.replace_feature(out)
+    assert residual is None
+    out_idx, out_num, out_bits, out_rank, nbr, shape, out_cap = _down_rules(x, conv.stride, conv.padding)
+    out = torch.empty((out_cap, conv.out_channels), dtype=feats.dtype, device=dev)
+    rc = _lib.lib().pn_spconv_forward(dt, _lib.ptr(feats), conv.in_channels, _lib.ptr(nbr), out_cap,
+                                      _lib.ptr(out_num), out_cap, _lib.ptr(w), _lib.ptr(scale),
+                                      _lib.ptr(shift), None, int(relu), _lib.ptr(out),
+                                      conv.out_channels, _lib.current_stream(dev))
+    _lib.check(rc, "pn_spconv_forward")
+    return SparseConvTensor(out, out_idx, shape, x.batch_size, out_num, out_bits, out_rank)
+
+
+class SparseSequential(SparseModule):
+    """spconv's SparseSequential: sparse modules get the tensor, plain modules get `.features`.
+    In eval mode a `conv, BatchNorm1d[, ReLU/SparseReLU]` run is dispatched as one fused kernel."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        from collections import OrderedDict
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(str(len(self._modules)) if name is None else name, module)
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseConvolution):
+                bn, relu, step = None, False, 1
+                if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d)
+                        and not mods[i + 1].training and not m.training):
+                    bn, step = mods[i + 1], 2
+                    if i + 2 < len(mods) and isinstance(mods[i + 2], (nn.ReLU, SparseReLU)):
+                        relu, step = True, 3
+                x = conv_forward(x, m, bn, relu)
+                i += step
+            elif isinstance(m, SparseModule):
+                x = m(x)
+                i += 1
+            elif isinstance(x, SparseConvTensor):
+                x = x.replace_feature(m(x.features_cap))
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+def to_dense(x: SparseConvTensor, channels_last=True):
+    feats = x.features_cap
+    H, W = x.spatial_shape
+    B, C = x.batch_size, feats.shape[1]
+    if channels_last:
+        out = torch.empty((B, H, W, C), dtype=feats.dtype, device=feats.device)
+    else:
+        out = torch.empty((B, C, H, W), dtype=feats.dtype, device=feats.device)
+    rc = _lib.lib().pn_sparse_to_dense(_dtype_code(feats), _lib.ptr(feats), _lib.ptr(x.indices_cap),
+                                       _lib.ptr(x.num_active), x.capacity, B, H, W, C,
+                                       int(channels_last), _lib.ptr(out),
+                                       _lib.current_stream(feats.device))
+    _lib.check(rc, "pn_sparse_to_dense")
+    return out.permute(0, 3, 1, 2) if channels_last else out

@@ -24,11 +24,46 @@ class SparseConvTensor:
         if num_active is None:
             num_active = torch.tensor([features.shape[0]], dtype=torch.int32, device=features.device)
         self.num_active = num_active
-        self.occ_bits = occ_bits      # uint64 words viewed as int64 [ceil(B*H*W/64)]
-        self.occ_rank = occ_rank      # int32 [words]
+        self._occ_bits = occ_bits     # uint64 words viewed as int64 [ceil(B*H*W/64)]
+        self._occ_rank = occ_rank     # int32 [words]
         self.indice_dict = {}         # indice_key -> rulebook (spconv's cache, base.py indice_key)
         self._keepalive = keepalive
         self._n_host = None
+
+    def _build_occupancy(self):
+        """Occupancy index for a tensor built spconv-style from (features, indices) only."""
+        from . import _lib
+        idx = self.indices_cap
+        if idx.device.type != "cuda":
+            raise _lib.PillarnetHipError("SparseConvTensor: indices must live on the GPU")
+        if idx.dtype != torch.int32 or not idx.is_contiguous():
+            self.indices_cap = idx = idx.to(torch.int32).contiguous()
+        H, W = self.spatial_shape
+        B = self.batch_size
+        words = (B * H * W + 63) // 64
+        L = _lib.lib()
+        bits = torch.empty(words, dtype=torch.int64, device=idx.device)
+        rank = torch.empty(words, dtype=torch.int32, device=idx.device)
+        cells = torch.zeros(1, dtype=torch.int32, device=idx.device)
+        sb = L.pn_occupancy_scratch_bytes(B, H, W)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=idx.device)
+        rc = L.pn_occupancy_from_indices(_lib.ptr(idx), _lib.ptr(self.num_active), self.capacity, B,
+                                         H, W, _lib.ptr(bits), _lib.ptr(rank), _lib.ptr(cells),
+                                         _lib.ptr(scratch), sb, _lib.current_stream(idx.device))
+        _lib.check(rc, "pn_occupancy_from_indices")
+        self._occ_bits, self._occ_rank = bits, rank
+
+    @property
+    def occ_bits(self):
+        if self._occ_bits is None:
+            self._build_occupancy()
+        return self._occ_bits
+
+    @property
+    def occ_rank(self):
+        if self._occ_rank is None:
+            self._build_occupancy()
+        return self._occ_rank
 
     # -- spconv API ---------------------------------------------------------------------------
     @property
@@ -57,7 +92,7 @@ class SparseConvTensor:
             full[: new_features.shape[0]] = new_features
             new_features = full
         out = SparseConvTensor(new_features, self.indices_cap, self.spatial_shape, self.batch_size,
-                               self.num_active, self.occ_bits, self.occ_rank, self._keepalive)
+                               self.num_active, self._occ_bits, self._occ_rank, self._keepalive)
         out.indice_dict = self.indice_dict
         out._n_host = self._n_host
         return out
