@@ -172,6 +172,50 @@ int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, 
                               int32_t* occ_rank, int32_t* active_cells_dev,
                               void* scratch, size_t scratch_bytes, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * (a9/a10) CenterHead.predict + post_processing + per-set rotated NMS, one call per frame batch.
+ *
+ * Replaces det3d/models/bbox_heads/center_head.py:217-413 (decode, class max, score / range
+ * mask, task merge), det3d/core/bbox/box_torch_ops.py:296-359 (rotate_nms_pcdet,
+ * rotate_class_nms_pcdet: rectified score, sort, top pre_max, [:post_max]) and
+ * det3d/ops/iou3d_nms/iou3d_nms_utils.py:30-34 (to_pcdet).
+ *
+ * One pnDecodeGroup per NMS problem of a sample: a task, or a (task, class) pair for
+ * use_multi_class_nms.  maps is that task's head output as [B, H*W, channels] fp32 with the
+ * channel order  reg(2) height(1) dim(3) rot(2: sin, cos) [vel(2)] [iou(1)] hm(num_classes).
+ * Output, per sample b: the kept boxes of its groups concatenated in group order --
+ * out_boxes [B, out_cap, box_dim] (x,y,z,dx,dy,dz,[vx,vy,]heading), out_scores, out_labels
+ * (+label_offset), out_num[b].  *status bit 0: more than 4096 cells tied inside one score bin
+ * at the pre_max cut-off (excess dropped).  Score ties are ordered by ascending cell index.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  const float* maps;
+  int32_t height, width, channels, num_classes;
+  int32_t has_vel, has_iou;
+  int32_t class_filter;    /* -1: all classes compete (rotate_nms_pcdet); k: only label k */
+  int32_t label_offset;    /* center_head.py:337-343 */
+  int32_t stride;          /* task stride (tasks[i].stride) */
+  float score_threshold;   /* test_cfg.score_threshold */
+  float rectifier;         /* test_cfg.rectifier: score^(1-r) * iou^r */
+  int32_t use_rectify;     /* report the rectified score */
+  float nms_threshold;
+  int32_t pre_max, post_max;
+} pnDecodeGroup;
+
+typedef struct {
+  int32_t batch;
+  float pillar_size, x_min, y_min;  /* fp32(pillar_size), fp32(point_cloud_range[0|1]) */
+  int32_t has_range;
+  float range[6];                   /* post_center_limit_range */
+} pnDecodeCommon;
+
+size_t pn_decode_workspace_bytes(const pnDecodeGroup* groups, int num_groups, int batch, int box_dim);
+int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
+                         const pnDecodeCommon* common, int box_dim, int out_cap,
+                         float* out_boxes, float* out_scores, int32_t* out_labels,
+                         int32_t* out_num, int32_t* status, void* workspace,
+                         size_t workspace_bytes, pnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

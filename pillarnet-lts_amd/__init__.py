@@ -2,5 +2,9 @@
 registry / operator API of VISION-SJTU/PillarNet-LTS."""
 from . import _lib  # noqa: F401
 from .spconv import SparseConvTensor  # noqa: F401
-
-__all__ = ["SparseConvTensor"]
+from .config import Config, ConfigDict  # noqa: F401
+from .registry import (BACKBONES, DETECTORS, HEADS, NECKS, READERS, Registry,  # noqa: F401
+                       build_from_cfg)
+from . import readers, backbones, necks, bbox_heads, detectors  # noqa: F401  (fill the registries)
+from .builder import (build_backbone, build_detector, build_head, build_neck,  # noqa: F401
+                      build_reader)

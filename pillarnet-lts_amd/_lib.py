@@ -28,6 +28,23 @@ class pnPillarGrid(ctypes.Structure):
     ]
 
 
+class pnDecodeGroup(ctypes.Structure):
+    _fields_ = [
+        ("maps", c_void_p), ("height", c_int32), ("width", c_int32), ("channels", c_int32),
+        ("num_classes", c_int32), ("has_vel", c_int32), ("has_iou", c_int32),
+        ("class_filter", c_int32), ("label_offset", c_int32), ("stride", c_int32),
+        ("score_threshold", c_float), ("rectifier", c_float), ("use_rectify", c_int32),
+        ("nms_threshold", c_float), ("pre_max", c_int32), ("post_max", c_int32),
+    ]
+
+
+class pnDecodeCommon(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("pillar_size", c_float), ("x_min", c_float), ("y_min", c_float),
+        ("has_range", c_int32), ("range", c_float * 6),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/pillarnet_hip.h
 SIGNATURES = {
     "pn_abi_version": (c_int, []),
@@ -58,6 +75,10 @@ SIGNATURES = {
     "pn_occupancy_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pn_occupancy_from_indices": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_decode_workspace_bytes": (c_size_t, [POINTER(pnDecodeGroup), c_int, c_int, c_int]),
+    "pn_centerhead_detect": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,184 @@
+"""HEADS registry: `CenterHead` + `SepHead` (det3d/models/bbox_heads/center_head.py:14-127).
+
+forward(): the reference's dense 3x3 conv stacks, run by PyTorch-ROCm (MIOpen).
+predict(): center_head.py:217-413 (decode, class max, score/range mask, per-task rotated NMS, task
+merge) is ONE call into the HIP library (`pn_centerhead_detect`): no boolean-index syncs, no host
+NMS loop; the only host sync is reading the per-sample box counts at the very end.
+"""
+import copy
+import ctypes
+import logging
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .nn_utils import Sequential, kaiming_init
+from .registry import HEADS
+
+
+class SepHead(nn.Module):
+    """center_head.py:14-51: one small conv tower per regression target + the heat map."""
+
+    def __init__(self, in_channels, heads, head_conv=64, init_bias=-2.19, **kwargs):
+        super().__init__(**kwargs)
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            fc = Sequential()
+            for _ in range(num_conv - 1):
+                fc.add(nn.Conv2d(in_channels, head_conv, 3, stride=1, padding=1, bias=True))
+                fc.add(nn.BatchNorm2d(head_conv, momentum=0.01, eps=1e-3))
+                fc.add(nn.ReLU())
+            fc.add(nn.Conv2d(head_conv, classes, 3, stride=1, padding=1, bias=True))
+            if "hm" in head:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        kaiming_init(m)
+            setattr(self, head, fc)
+
+    def forward(self, x):
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+# channel order pn_centerhead_detect expects (include/pillarnet_hip.h)
+_ORDER = ("reg", "height", "dim", "rot", "vel", "iou", "hm")
+
+
+@HEADS.register_module
+class CenterHead(nn.Module):
+    def __init__(self, tasks: List[dict], in_channels: List, code_weights: List, common_heads=dict(),
+                 logger=None, share_channel=64, reg_iou=None, pillar_size=0.1,
+                 point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4]):
+        super().__init__()
+        self.num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.task_strides = [int(t["stride"]) for t in tasks]
+        self.code_weights = code_weights
+        self.pillar_size = pillar_size
+        self.point_cloud_range = point_cloud_range
+        # feature maps arrive ordered by descending stride (center_head.py:75-79)
+        strides = sorted(set(self.task_strides), reverse=True)
+        assert len(in_channels) == len(strides)
+        self.task_idx = [strides.index(s) for s in self.task_strides]
+        self.use_iou = "iou" in common_heads
+        self.use_reg_iou = reg_iou is not None
+        self.reg_iou = reg_iou
+        self.box_n_dim = 9 if "vel" in common_heads else 7
+        self.use_direction_classifier = False
+        self.logger = logger or logging.getLogger("CenterHead")
+        self.logger.info(f"num_classes: {self.num_classes}")
+        self.share_convs = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(c, share_channel, 3, padding=1, bias=True),
+                          nn.BatchNorm2d(share_channel, momentum=0.01, eps=1e-3), nn.ReLU())
+            for c in in_channels)
+        self.task_heads = nn.ModuleList()
+        for n in self.num_classes:
+            heads = copy.deepcopy(common_heads)
+            heads.update(dict(hm=(n, 2)))
+            self.task_heads.append(SepHead(share_channel, heads))
+        self.logger.info("Finish CenterHead Initialization")
+
+    def forward(self, x):
+        assert len(x) == len(self.share_convs)
+        shared = [conv(x[k]) for k, conv in enumerate(self.share_convs)]
+        return [head(shared[self.task_idx[k]]) for k, head in enumerate(self.task_heads)]
+
+    def loss(self, example, preds_dicts, train_cfg, **kwargs):
+        from .losses import center_head_loss
+        return center_head_loss(self, example, preds_dicts, train_cfg)
+
+    # ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _task_param(value, task_id, cls=None):
+        """test_cfg entries are scalars, or per-task lists (after set_by_task_cfg) of per-class
+        lists; returns the entry for (task, class)."""
+        if isinstance(value, (list, tuple)):
+            value = value[task_id]
+        if cls is not None and isinstance(value, (list, tuple)):
+            value = value[cls]
+        return value
+
+    @torch.no_grad()
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        if test_cfg.get("double_flip", False):
+            raise NotImplementedError("double_flip test-time augmentation is not built on the HIP path yet")
+        if test_cfg.get("circular_nms", False):
+            raise NotImplementedError("circular_nms (CPU numba in the reference) is not built")
+        nms_cfg = test_cfg["nms"]
+        multi_class = bool(nms_cfg.get("use_multi_class_nms", False))
+        if not multi_class and not nms_cfg.get("use_rotate_nms", False):
+            raise NotImplementedError
+        dev = preds_dicts[0]["hm"].device
+        if dev.type != "cuda":
+            raise _lib.PillarnetHipError("CenterHead.predict: maps must live on the GPU (no CPU fallback)")
+        B = preds_dicts[0]["hm"].shape[0]
+        has_vel = int("vel" in preds_dicts[0])
+        keep_alive, groups = [], []
+        label_offset, out_cap = 0, 0
+        for t, pd in enumerate(preds_dicts):
+            has_iou = int("iou" in pd)
+            # one [B, H*W, C] fp32 map per task (tiny: C ~ 12 channels at head resolution)
+            parts = [pd[k] for k in _ORDER if k in pd]
+            m = torch.cat([p.float() for p in parts], dim=1).permute(0, 2, 3, 1).contiguous()
+            keep_alive.append(m)
+            H, W, CH = m.shape[1], m.shape[2], m.shape[3]
+            classes = range(self.num_classes[t]) if multi_class else [None]
+            for k in classes:
+                g = _lib.pnDecodeGroup()
+                g.maps = m.data_ptr()
+                g.height, g.width, g.channels, g.num_classes = H, W, CH, self.num_classes[t]
+                g.has_vel, g.has_iou = has_vel, has_iou
+                g.class_filter = -1 if k is None else k
+                g.label_offset = label_offset
+                g.stride = self.task_strides[t]
+                g.score_threshold = float(test_cfg["score_threshold"])
+                g.rectifier = float(self._task_param(test_cfg["rectifier"], t, k))
+                use_rect = test_cfg.get("use_rectify", False) if multi_class else False
+                g.use_rectify = int(bool(self._task_param(use_rect, t, k))) if use_rect else 0
+                g.nms_threshold = float(self._task_param(nms_cfg["nms_iou_threshold"], t, k))
+                g.pre_max = int(self._task_param(nms_cfg["nms_pre_max_size"], t, k))
+                g.post_max = int(self._task_param(nms_cfg["nms_post_max_size"], t, k))
+                out_cap += g.post_max
+                groups.append(g)
+            label_offset += self.num_classes[t]
+        G = (_lib.pnDecodeGroup * len(groups))(*groups)
+        common = _lib.pnDecodeCommon()
+        common.batch = B
+        common.pillar_size = float(np.float32(self.pillar_size))
+        common.x_min = float(np.float32(self.point_cloud_range[0]))
+        common.y_min = float(np.float32(self.point_cloud_range[1]))
+        rng = list(test_cfg.get("post_center_limit_range", []))
+        common.has_range = int(len(rng) > 0)
+        for i, v in enumerate(rng[:6]):
+            common.range[i] = float(np.float32(v))
+        L = _lib.lib()
+        nd = self.box_n_dim
+        wsb = L.pn_decode_workspace_bytes(G, len(groups), B, nd)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        boxes = torch.empty((B, out_cap, nd), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, out_cap), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, out_cap), dtype=torch.int32, device=dev)
+        num = torch.zeros(B + 1, dtype=torch.int32, device=dev)   # [B] counts + status word
+        rc = L.pn_centerhead_detect(G, len(groups), ctypes.byref(common), nd, out_cap, _lib.ptr(boxes),
+                                    _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(num),
+                                    ctypes.c_void_p(num.data_ptr() + 4 * B), _lib.ptr(ws), wsb,
+                                    _lib.current_stream(dev))
+        _lib.check(rc, "pn_centerhead_detect")
+        if kwargs.get("raw", False):   # fixed-capacity tensors, no host sync
+            return boxes, scores, labels, num
+        counts = num.cpu().tolist()   # the frame's single device->host sync
+        if counts[B] & 1:
+            self.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+        metas = example.get("metadata", None) if isinstance(example, dict) else None
+        if not metas:
+            metas = [None] * B
+        out = []
+        for b in range(B):
+            n = counts[b]
+            out.append({"box3d_lidar": boxes[b, :n], "scores": scores[b, :n],
+                        "label_preds": labels[b, :n].long(), "metadata": metas[b]})
+        return out

@@ -1,0 +1,103 @@
+"""DETECTORS registry: `PillarNet`, `SingleStageDetector`, `BaseDetector`
+(det3d/models/detectors/{base,single_stage,pillarnet}.py)."""
+import torch
+import torch.nn as nn
+
+from . import builder
+from .center_utils import set_by_task_cfg
+from .registry import DETECTORS
+
+
+class BaseDetector(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fp16_enabled = False
+
+    with_reader = property(lambda self: getattr(self, "reader", None) is not None)
+    with_neck = property(lambda self: getattr(self, "neck", None) is not None)
+    with_shared_head = property(lambda self: getattr(self, "shared_head", None) is not None)
+    with_bbox = property(lambda self: getattr(self, "bbox_head", None) is not None)
+    with_mask = property(lambda self: getattr(self, "mask_head", None) is not None)
+
+
+@DETECTORS.register_module
+class SingleStageDetector(BaseDetector):
+    def __init__(self, reader, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__()
+        self.reader = builder.build_reader(reader)
+        self.backbone = builder.build_backbone(backbone)
+        if neck is not None:
+            self.neck = builder.build_neck(neck)
+        self.bbox_head = builder.build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.compute_dtype = torch.float32
+        self.init_weights(pretrained=pretrained)
+
+    def init_weights(self, pretrained=None):
+        if pretrained is None:
+            return
+        from .checkpoint import load_checkpoint
+        try:
+            load_checkpoint(self, pretrained, strict=False)
+            print("init weight from {}".format(pretrained))
+        except Exception:
+            print("no pretrained model at {}".format(pretrained))
+
+    def extract_feat(self, data):
+        x = self.backbone(self.reader(data))
+        return self.neck(x) if self.with_neck else x
+
+    def forward(self, example, return_loss=True, **kwargs):
+        pass
+
+    # -- MI355X inference set-up ----------------------------------------------------------------
+    def to_inference(self, dtype=torch.bfloat16, device="cuda"):
+        """eval mode; dense conv5 / neck / head cast to `dtype` in channels-last (MIOpen NHWC);
+        the sparse stages pick their dtype up from the feature rows.  fp32 keeps everything fp32."""
+        self.eval().to(device)
+        self.compute_dtype = dtype
+        dense = [getattr(self.backbone, "conv5", None), getattr(self, "neck", None), self.bbox_head]
+        for m in dense:
+            if m is not None:
+                m.to(dtype=dtype, memory_format=torch.channels_last)
+        return self
+
+
+@DETECTORS.register_module
+class PillarNet(SingleStageDetector):
+    """pillarnet.py:6-82."""
+
+    def __init__(self, reader, backbone, neck, bbox_head, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
+        post = self.test_cfg.nms.nms_post_max_size
+        self.NMS_POST_MAXSIZE = sum(post) if isinstance(post, list) else post
+        self.num_classes = self.bbox_head.num_classes
+        self.test_cfg = set_by_task_cfg(self.test_cfg, self.bbox_head.num_classes)
+
+    def extract_feat(self, data):
+        sp = self.reader(data)
+        if self.compute_dtype != sp.features_cap.dtype:
+            sp = sp.replace_feature(sp.features_cap.to(self.compute_dtype))
+        pillar_features = self.backbone(sp)
+        bev_features = self.neck(pillar_features) if self.with_neck else None
+        return bev_features, pillar_features
+
+    def forward(self, example, return_loss=True, **kwargs):
+        data = dict(points=example["points"], batch_size=len(example["metadata"]))
+        bev_features, _ = self.extract_feat(data)
+        preds = self.bbox_head(bev_features)
+        if return_loss:
+            return self.bbox_head.loss(example, preds, self.train_cfg)
+        return self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)
+
+    def forward_two_stage(self, example, return_loss=True, **kwargs):
+        data = dict(points=example["points"], batch_size=len(example["metadata"]))
+        bev_features, backbone_features = self.extract_feat(data)
+        preds = self.bbox_head(bev_features)
+        detached = [{k: v.detach() for k, v in p.items()} for p in preds]
+        boxes = self.bbox_head.predict(example, detached, self.test_cfg)
+        loss = self.bbox_head.loss(example, preds, self.train_cfg) if return_loss else None
+        return boxes, bev_features, backbone_features, loss

@@ -1,0 +1,62 @@
+"""Name -> class registries and `build_from_cfg`, with the behaviour the reference's configs rely on
+(det3d/utils/registry.py:6-78, det3d/models/registry.py:3-11): same registry names, same error
+types (KeyError for an unknown or duplicate type, TypeError for a bad `type`, AssertionError when
+`type` is missing)."""
+import inspect
+
+
+class Registry:
+    def __init__(self, name):
+        self._name = name
+        self._module_dict = {}
+
+    def __repr__(self):
+        return f"{type(self).__name__}(name={self._name}, items={list(self._module_dict)})"
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def module_dict(self):
+        return self._module_dict
+
+    def get(self, key):
+        return self._module_dict.get(key)
+
+    def register_module(self, cls):
+        if not inspect.isclass(cls):
+            raise TypeError(f"module must be a class, but got {type(cls)}")
+        if cls.__name__ in self._module_dict:
+            raise KeyError(f"{cls.__name__} is already registered in {self._name}")
+        self._module_dict[cls.__name__] = cls
+        return cls
+
+
+def build_from_cfg(cfg, registry, default_args=None):
+    assert isinstance(cfg, dict) and "type" in cfg
+    assert isinstance(default_args, dict) or default_args is None
+    args = dict(cfg)
+    kind = args.pop("type")
+    if isinstance(kind, str):
+        cls = registry.get(kind)
+        if cls is None:
+            raise KeyError(f"{kind} is not in the {registry.name} registry")
+    elif inspect.isclass(kind):
+        cls = kind
+    else:
+        raise TypeError(f"type must be a str or valid type, but got {type(kind)}")
+    for k, v in (default_args or {}).items():
+        args.setdefault(k, v)
+    return cls(**args)
+
+
+READERS = Registry("reader")
+BACKBONES = Registry("backbone")
+NECKS = Registry("neck")
+HEADS = Registry("head")
+LOSSES = Registry("loss")
+DETECTORS = Registry("detector")
+SECOND_STAGE = Registry("second_stage")
+ROI_HEAD = Registry("roi_head")
+POINT_HEAD = Registry("point_head")
