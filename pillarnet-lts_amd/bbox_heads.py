@@ -41,7 +41,23 @@ class SepHead(nn.Module):
             setattr(self, head, fc)
 
     def forward(self, x):
-        return {head: getattr(self, head)(x) for head in self.heads}
+        out = {}
+        for head in self.heads:
+            fc = getattr(self, head)
+            last = fc[-1]
+            y = x
+            for m in list(fc._modules.values())[:-1]:
+                y = m(y)
+            # the output conv may be kept in fp32 while the tower runs in bf16 (to_inference):
+            # bf16 heat-map logits collapse thousands of cells onto identical scores
+            if y.dtype != last.weight.dtype:
+                y = y.to(last.weight.dtype)
+            out[head] = last(y)
+        return out
+
+    def keep_output_convs_fp32(self):
+        for head in self.heads:
+            getattr(self, head)[-1].float()
 
 
 # channel order pn_centerhead_detect expects (include/pillarnet_hip.h)

@@ -62,6 +62,8 @@ class SingleStageDetector(BaseDetector):
         for m in dense:
             if m is not None:
                 m.to(dtype=dtype, memory_format=torch.channels_last)
+        for th in getattr(self.bbox_head, "task_heads", []):
+            th.keep_output_convs_fp32()
         return self
 
 
