@@ -122,7 +122,9 @@ def _down_rules(x: SparseConvTensor, stride, pad):
     H, W = x.spatial_shape
     Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     B = x.batch_size
-    out_cap = max(1, min(x.capacity, B * Ho * Wo))
+    # an input site feeds ceil(3/stride)^2 output cells at most (4 for k3 s2)
+    fan = ((3 + stride - 1) // stride) ** 2
+    out_cap = max(1, min(x.capacity * fan, B * Ho * Wo))
     words = (B * Ho * Wo + 63) // 64
     L = _lib.lib()
     out_idx = torch.empty((out_cap, 3), dtype=torch.int32, device=dev)
