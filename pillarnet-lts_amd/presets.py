@@ -44,7 +44,7 @@ def waymo_pillarnet34_fpn():
     tasks = [dict(stride=8, class_names=["VEHICLE"]), dict(stride=4, class_names=["PEDESTRIAN", "CYCLIST"])]
     pillar, rng = 0.1, [-75.2, -75.2, -2, 75.2, 75.2, 4.0]
     model = dict(
-        type="PillarNet", pretrained=None,
+        type="PillarNet",
         reader=dict(type="DynamicPFE", in_channels=5, num_filters=(32,), pillar_size=pillar, pc_range=rng),
         backbone=dict(type="PillarResNet34", in_channels=32),
         neck=dict(type="RPNG", layer_nums=[5, 5], num_filters=[256, 128], in_channels=[256, 256, 128],

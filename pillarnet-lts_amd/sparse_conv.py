@@ -166,10 +166,10 @@ def _down_rules(x: SparseConvTensor, stride, pad):
 def conv_forward(x: SparseConvTensor, conv: SparseConvolution, bn=None, relu=False, residual=None):
     """conv (+ folded eval-mode norm) (+ residual rows) (+ ReLU) as one kernel."""
     feats = x.features_cap
-    if feats.device.type != "cuda":
-        raise _lib.PillarnetHipError("sparse conv: features must live on the GPU (no CPU fallback)")
     if conv.training or (bn is not None and bn.training):
         raise NotImplementedError("training-mode sparse conv / BatchNorm is not built yet; call .eval()")
+    if feats.device.type != "cuda":
+        raise _lib.PillarnetHipError("sparse conv: features must live on the GPU (no CPU fallback)")
     dt = _dtype_code(feats)
     w, scale, shift = conv.packed(feats.dtype, bn)
     dev = feats.device

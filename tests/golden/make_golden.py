@@ -1,0 +1,323 @@
+"""Generates the golden fixtures under tests/golden/ FROM THE REFERENCE ITSELF.  Runs only in the
+build container (needs /root/reference and, for the IoU vectors, oracle/_ref built from the
+reference's iou3d_cpu.cpp).  The fixtures are data only: seeded inputs, the weights that were
+used, and the outputs the reference's own code produced.
+
+Reference code executed here (imported from /root/reference, nothing copied):
+  det3d.models.necks.rpn.RPNV1 / RPNG                 -> dense_neck.npz
+  det3d.models.bbox_heads.center_head.CenterHead      -> dense_head.npz (forward), decode.npz (predict)
+  det3d.core.utils.center_utils.set_by_task_cfg       -> test_cfg.json
+  det3d.torchie.Config.fromfile on the 8 live configs -> configs.json
+  det3d.models.readers.dynamic_pillar_encoder.DynamicPFE.forward (coordinate + mask step, torch-CPU)
+  det3d.ops.pillar_ops.pillar_modules.PillarMaxPooling.shared_mlps   -> reader.npz
+  det3d/ops/iou3d_nms/src/iou3d_cpu.cpp (compiled, oracle/_ref)      -> iou3d.npz
+
+The reference imports packages this image lacks (numba, addict, spconv, torchvision, terminaltables,
+its own un-built CUDA extensions); they are replaced by inert in-process module objects so that the
+pure-PyTorch parts import.  `rotate_nms_pcdet` calls `.cuda()` and the CUDA-only `nms_gpu`; for the
+decode fixture `.cuda()` is made a no-op and `nms_gpu` is served by the compiled-reference-pinned C
+oracle (greedy pass restated from iou3d_nms.cpp:139-156).
+"""
+import collections
+import collections.abc
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def install_stubs():
+    for name in ("Iterable", "Sequence", "Mapping"):
+        if not hasattr(collections, name):
+            setattr(collections, name, getattr(collections.abc, name))
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__spec__ = types.SimpleNamespace(name=name, loader=None, origin="stub", submodule_search_locations=[])
+        m.__path__ = []
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def passthrough(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    numba = mod("numba", jit=passthrough, njit=passthrough, prange=range)
+    mod("numba.cuda")
+    numba.cuda = sys.modules["numba.cuda"]
+
+    class AttrDict(dict):
+        def __init__(self, *a, **k):
+            super().__init__()
+            for kk, v in dict(*a, **k).items():
+                self[kk] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, AttrDict):
+                v = type(self)(v)
+            elif isinstance(v, (list, tuple)):
+                v = type(v)(type(self)(x) if isinstance(x, dict) and not isinstance(x, AttrDict) else x for x in v)
+            super().__setitem__(k, v)
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                return self.__missing__(k)
+
+        def __missing__(self, k):
+            raise KeyError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    mod("addict", Dict=AttrDict)
+    mod("terminaltables", AsciiTable=object)
+    tv = mod("torchvision")
+    mod("torchvision.models")
+    tv.models = sys.modules["torchvision.models"]
+
+    class _Any(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    sp = mod("spconv")
+    spp = mod("spconv.pytorch", SparseConvTensor=type("SparseConvTensor", (), {}), SubMConv2d=_Any,
+              SubMConv3d=_Any, SparseConv2d=_Any, SparseConv3d=_Any, SparseModule=torch.nn.Module,
+              SparseSequential=torch.nn.Sequential, SparseInverseConv2d=_Any, SparseReLU=torch.nn.ReLU)
+    sp.pytorch = spp
+    mod("spconv.utils")
+    mod("einops")
+    mod("einops.layers")
+    mod("einops.layers.torch", Rearrange=_Any, Reduce=_Any)
+    mod("pyquaternion", Quaternion=object)
+    mod("cv2")
+    mod("shapely")
+    mod("shapely.geometry", Polygon=object)
+    for ext in ("det3d.ops.pillar_ops.pillar_cuda", "det3d.ops.iou3d_nms.iou3d_nms_cuda",
+                "det3d.ops.roiaware_pool3d.roiaware_pool3d_cuda"):
+        m = types.ModuleType(ext)
+        sys.modules[ext] = m
+    sys.path.insert(0, REF)
+
+
+def to_np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def randomize_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.4 + 0.8)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def golden_iou3d():
+    from oracle import iou3d
+    from pillarnet_lts_amd import synth
+    assert iou3d.ref_lib() is not None, "build oracle/_ref first (python oracle/build_ref.py)"
+    a = synth.nms_boxes(120, seed=1, cluster=2.0)
+    b = synth.nms_boxes(90, seed=2, cluster=2.0)
+    b[:60, :2] = a[:60, :2] + 0.3
+    iou = iou3d.ref_iou_matrix(a, b)
+    out = dict(boxes_a=a, boxes_b=b, iou_ab=iou, known_a=np.array([[0, 0, 0, 4, 2, 1.5, 0.3]], np.float32),
+               known_b=np.array([[0.5, 0.2, 0, 4, 2, 1.5, -0.2]], np.float32))
+    out["known_iou"] = iou3d.ref_iou_matrix(out["known_a"], out["known_b"])
+    # keep lists: greedy pass (iou3d_nms.cpp:139-156) over the REFERENCE's IoU matrix
+    for n in (1, 63, 64, 65, 200):
+        for thr in (0.2, 0.55, 0.8):
+            bx = synth.nms_boxes(n, seed=400 + n, cluster=1.5)
+            m = iou3d.ref_iou_matrix(bx, bx)
+            removed = np.zeros(n, bool)
+            keep = []
+            for i in range(n):
+                if removed[i]:
+                    continue
+                keep.append(i)
+                removed[i + 1:] |= m[i, i + 1:] > np.float32(thr)
+            tag = f"nms_{n}_{int(thr * 100)}"
+            out[tag + "_boxes"] = bx
+            out[tag + "_keep"] = np.asarray(keep, np.int64)
+    save("iou3d.npz", **out)
+
+
+def golden_dense():
+    import logging
+    from det3d.models.necks.rpn import RPNG, RPNV1
+    from det3d.models.bbox_heads.center_head import CenterHead
+    from det3d.torchie import Config
+    torch.manual_seed(7)
+    log = logging.getLogger("golden")
+    neck = RPNV1(layer_nums=[2, 1], num_filters=24, in_channels=[16, 8], logger=log).eval()
+    randomize_bn(neck, 3)
+    c4, c5 = torch.randn(2, 8, 12, 10), torch.randn(2, 16, 6, 5)
+    with torch.no_grad():
+        y = neck({"conv4": c4, "conv5": c5})
+    arrays = {"rpnv1.in.conv4": c4.numpy(), "rpnv1.in.conv5": c5.numpy(), "rpnv1.out.0": y[0].numpy()}
+    arrays.update({"rpnv1.sd." + k: v for k, v in to_np(neck.state_dict()).items()})
+    g = RPNG(layer_nums=[1, 2], in_channels=[16, 8, 8], num_filters=[12, 8], logger=log).eval()
+    randomize_bn(g, 4)
+    c3 = torch.randn(1, 8, 16, 12)
+    c4g, c5g = torch.randn(1, 8, 8, 6), torch.randn(1, 16, 4, 3)
+    with torch.no_grad():
+        yg = g({"conv3": c3, "conv4": c4g, "conv5": c5g})
+    arrays.update({"rpng.in.conv3": c3.numpy(), "rpng.in.conv4": c4g.numpy(), "rpng.in.conv5": c5g.numpy(),
+                   "rpng.out.0": yg[0].numpy(), "rpng.out.1": yg[1].numpy()})
+    arrays.update({"rpng.sd." + k: v for k, v in to_np(g.state_dict()).items()})
+    save("dense_neck.npz", **arrays)
+
+    tasks = [Config(dict(stride=8, class_names=["car"]))._cfg_dict,
+             Config(dict(stride=8, class_names=["bus", "trailer"]))._cfg_dict]
+    heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)}
+    head = CenterHead(tasks=tasks, in_channels=[24], code_weights=[1.0] * 10, common_heads=heads, logger=log,
+                      share_channel=16, reg_iou="GIoU", pillar_size=0.075,
+                      point_cloud_range=[-6, -4.8, -5.0, 6, 4.8, 3.0]).eval()
+    randomize_bn(head, 5)
+    with torch.no_grad():
+        for th in head.task_heads:
+            th.hm[-1].weight.mul_(6.0)
+    x = torch.randn(2, 24, 16, 20)
+    with torch.no_grad():
+        preds = head((x,))
+    arrays = {"in.0": x.numpy()}
+    for t, pd in enumerate(preds):
+        for k, v in pd.items():
+            arrays[f"out.{t}.{k}"] = v.numpy()
+    arrays.update({"sd." + k: v for k, v in to_np(head.state_dict()).items()})
+    save("dense_head.npz", **arrays)
+    return head, preds
+
+
+def golden_decode(head, preds):
+    """CenterHead.predict on CPU: `.cuda()` neutralised, nms_gpu served by the pinned C oracle."""
+    from oracle import iou3d
+    from det3d.core.bbox import box_torch_ops
+    from det3d.core.utils.center_utils import set_by_task_cfg
+    from det3d.torchie import Config
+    ext = sys.modules["det3d.ops.iou3d_nms.iou3d_nms_cuda"]
+
+    def nms_gpu(boxes, keep, thresh):
+        k, _ = iou3d.nms(boxes.numpy(), float(thresh))
+        keep[: len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    ext.nms_gpu = nms_gpu
+    box_torch_ops.iou3d_nms_cuda = ext
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    test_cfg = Config(dict(nms=dict(use_rotate_nms=True, nms_pre_max_size=100, nms_post_max_size=20,
+                                    nms_iou_threshold=0.2), rectifier=0, score_threshold=0.1, double_flip=False,
+                           post_center_limit_range=[-7, -6, -10.0, 7, 6, 10.0]))._cfg_dict
+    test_cfg = set_by_task_cfg(test_cfg, head.num_classes)
+    p2 = [{k: v.clone() for k, v in pd.items()} for pd in preds]
+    out = head.predict({"metadata": [None, None]}, p2, test_cfg)
+    arrays = {}
+    for b, d in enumerate(out):
+        arrays[f"{b}.box3d_lidar"] = d["box3d_lidar"].numpy()
+        arrays[f"{b}.scores"] = d["scores"].numpy()
+        arrays[f"{b}.label_preds"] = d["label_preds"].numpy()
+    save("decode.npz", **arrays)
+    with open(os.path.join(HERE, "decode_test_cfg.json"), "w") as f:
+        json.dump(json.loads(json.dumps(test_cfg)), f, indent=1)
+
+
+def golden_cfg():
+    from det3d.core.utils.center_utils import set_by_task_cfg
+    from det3d.torchie import Config
+    out = {}
+    for sub in ("pillarnet", "pillarrcnn"):
+        d = os.path.join(REF, "configs", sub)
+        for fn in sorted(os.listdir(d)):
+            if not fn.endswith(".py"):
+                continue
+            cfg = Config.fromfile(os.path.join(d, fn))
+
+            def clean(o):
+                if isinstance(o, dict):
+                    return {k: clean(v) for k, v in o.items() if k != "logger"}
+                if isinstance(o, (list, tuple)):
+                    return [clean(v) for v in o]
+                if isinstance(o, (int, float, str, bool)) or o is None:
+                    return o
+                return repr(o)
+            model = clean(cfg.model)
+            test_cfg = clean(cfg.test_cfg)
+            ncls = [len(t["class_names"]) for t in cfg.model.get("bbox_head", cfg.model.get("first_stage_cfg", {}).get("bbox_head", {})).get("tasks", [])] \
+                if "bbox_head" in cfg.model else []
+            regrouped = clean(set_by_task_cfg(Config(json.loads(json.dumps(test_cfg)))._cfg_dict, ncls)) if ncls else None
+            out[f"{sub}/{fn}"] = dict(model=model, test_cfg=test_cfg, test_cfg_by_task=regrouped)
+    with open(os.path.join(HERE, "configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote configs.json", len(out), "configs")
+
+
+def golden_reader():
+    """DynamicPFE.forward's coordinate/mask step (torch-CPU => true division) and the PFN MLP."""
+    from det3d.ops.pillar_ops.pillar_modules import PillarMaxPooling
+    from det3d.models.readers.dynamic_pillar_encoder import DynamicPFE
+    from pillarnet_lts_amd import synth
+    captured = {}
+
+    class Capture(torch.nn.Module):
+        height, width = 1440, 1440
+
+        def forward(self, pts_xy, pts_batch_cnt, pts_features):
+            captured.update(pts_xy=pts_xy.numpy(), cnt=pts_batch_cnt.numpy(), feats=pts_features.numpy())
+            return None
+
+    reader = DynamicPFE.__new__(DynamicPFE)
+    torch.nn.Module.__init__(reader)
+    reader.pillar_size, reader.pc_range = 0.075, [-54, -54, -5.0, 54, 54, 3.0]
+    reader.pfn_layers = Capture()
+    reader.height = reader.width = 1440
+    pts = [synth.nusc_sweep(3000, seed=21), synth.nusc_sweep(2000, seed=22)]
+    edges = (np.arange(0, 1441, 7, dtype=np.float64) * 0.075 - 54.0).astype(np.float32)
+    extra = np.zeros((edges.size * 3, 5), np.float32)
+    extra[:, 0] = np.concatenate([edges, np.nextafter(edges, np.float32(99)), np.nextafter(edges, np.float32(-99))])
+    extra[:, 1] = extra[::-1, 0]
+    pts[1] = np.concatenate([pts[1], extra])
+    reader.forward({"points": [torch.from_numpy(p) for p in pts]})
+    torch.manual_seed(11)
+    pfn = PillarMaxPooling.__new__(PillarMaxPooling)
+    torch.nn.Module.__init__(pfn)
+    pfn.shared_mlps = torch.nn.Sequential(torch.nn.Linear(7, 32, bias=False),
+                                          torch.nn.BatchNorm1d(32, momentum=0.01, eps=1e-3), torch.nn.ReLU())
+    PillarMaxPooling.init_weights(pfn, weight_init="kaiming")
+    randomize_bn(pfn, 6)
+    pfn.eval()
+    x = torch.randn(500, 7)
+    with torch.no_grad():
+        y = pfn.shared_mlps(x)
+    arrays = {"points.0": pts[0], "points.1": pts[1], "pts_xy": captured["pts_xy"], "pts_batch_cnt": captured["cnt"],
+              "pts_features": captured["feats"], "mlp.in": x.numpy(), "mlp.out": y.numpy()}
+    arrays.update({"mlp.sd." + k: v for k, v in to_np(pfn.shared_mlps.state_dict()).items()})
+    save("reader.npz", **arrays)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference tree is required"
+    install_stubs()
+    golden_iou3d()
+    golden_cfg()
+    golden_reader()
+    head, preds = golden_dense()
+    golden_decode(head, preds)

@@ -1,0 +1,193 @@
+"""Host-side logic on the CPU: registry / config / builder behaviour, state-dict contract, presets
+vs the reference's live configs, no-CPU-fallback guarantees."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pillarnet_lts_amd as P
+from pillarnet_lts_amd import _lib, pillar_ops, presets, sparse_conv
+from pillarnet_lts_amd.center_utils import set_by_task_cfg
+from pillarnet_lts_amd.registry import Registry, build_from_cfg
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+REF_CFG = "/root/reference/configs"
+
+
+def test_registry_errors():
+    r = Registry("thing")
+
+    @r.register_module
+    class A:
+        def __init__(self, x=1, train_cfg=None):
+            self.x, self.train_cfg = x, train_cfg
+
+    with pytest.raises(KeyError):
+        r.register_module(A)
+    with pytest.raises(TypeError):
+        r.register_module(lambda: 0)
+    with pytest.raises(KeyError, match="is not in the thing registry"):
+        build_from_cfg(dict(type="Nope"), r)
+    with pytest.raises(TypeError):
+        build_from_cfg(dict(type=3), r)
+    with pytest.raises(AssertionError):
+        build_from_cfg(dict(x=1), r)
+    obj = build_from_cfg(dict(type="A", x=5), r, dict(train_cfg="t", x=9))
+    assert obj.x == 5 and obj.train_cfg == "t"
+    assert build_from_cfg(dict(type=A), r).x == 1
+
+
+def test_registered_names():
+    assert set(P.READERS.module_dict) >= {"DynamicPFE"}
+    assert set(P.BACKBONES.module_dict) >= {"PillarResNet18", "PillarResNet18S", "PillarResNet34", "PillarResNet34S"}
+    assert set(P.NECKS.module_dict) >= {"RPN", "RPNV1", "RPNV2", "RPNG", "RPNGV2"}
+    assert set(P.HEADS.module_dict) >= {"CenterHead"}
+    assert set(P.DETECTORS.module_dict) >= {"PillarNet", "SingleStageDetector"}
+
+
+def test_config_dict_semantics(tmp_path):
+    c = P.ConfigDict(a=1, b=dict(c=[dict(d=2)]))
+    assert c.b.c[0].d == 2
+    with pytest.raises(AttributeError):
+        c.nope
+    with pytest.raises(KeyError):
+        c["nope"]
+    f = tmp_path / "cfg_x.py"
+    f.write_text("import itertools\nv = 3\nm = dict(type='T', k=[1, 2])\nn = __file__[-8:-3]\n")
+    cfg = P.Config.fromfile(str(f))
+    assert cfg.v == 3 and cfg.m.type == "T" and cfg.n == "cfg_x" and "itertools" not in cfg
+    assert cfg.text.startswith("import itertools")
+    with pytest.raises(FileNotFoundError):
+        P.Config.fromfile(str(tmp_path / "missing.py"))
+
+
+@pytest.fixture(scope="module")
+def nusc_model():
+    torch.manual_seed(0)
+    return presets.build(presets.nusc_pillarnet18())
+
+
+def test_state_dict_contract(nusc_model):
+    sd = nusc_model.state_dict()
+    n = sum(p.numel() for p in nusc_model.parameters())
+    assert n == 288 + 5307488 + 7936512 + 1522054      # reader + backbone + RPNV1 + CenterHead
+    shapes = {
+        "reader.pfn_layers.shared_mlps.0.weight": (32, 7),
+        "reader.pfn_layers.shared_mlps.1.running_var": (32,),
+        "backbone.conv1.0.conv0.0.weight": (32, 3, 3, 32),   # spconv 2.x KRSC
+        "backbone.conv1.0.conv0.0.bias": (32,),
+        "backbone.conv1.1.conv2.1.weight": (32,),
+        "backbone.conv2.0.weight": (64, 3, 3, 32),
+        "backbone.conv2.1.running_mean": (64,),
+        "backbone.conv2.4.conv1.0.weight": (64, 3, 3, 64),
+        "backbone.conv4.3.conv2.0.bias": (256,),
+        "backbone.conv5.0.weight": (256, 256, 3, 3),
+        "backbone.conv5.4.0.weight": (256, 256, 3, 3),
+        "neck.block_5.1.weight": (256, 256, 3, 3),
+        "neck.deblock_5.0.weight": (256, 256, 2, 2),
+        "neck.block_4.1.weight": (256, 512, 3, 3),
+        "neck.block_4.16.weight": (256, 256, 3, 3),
+        "bbox_head.share_convs.0.0.weight": (64, 256, 3, 3),
+        "bbox_head.task_heads.0.hm.3.bias": (1,),
+        "bbox_head.task_heads.5.vel.3.weight": (2, 64, 3, 3),
+    }
+    for k, s in shapes.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == s, (k, tuple(sd[k].shape))
+    assert "backbone.conv2.0.bias" not in sd            # SparseConv2d(..., bias=False)
+    assert float(sd["bbox_head.task_heads.0.hm.3.bias"][0]) == pytest.approx(-2.19)
+    assert nusc_model.reader.height == 1440 and nusc_model.reader.width == 1440
+    assert nusc_model.backbone.backbone_channels["conv4"] == 256 and nusc_model.backbone.backbone_strides["conv5"] == 16
+    assert nusc_model.NMS_POST_MAXSIZE == 83 and nusc_model.bbox_head.num_classes == [1, 2, 2, 1, 2, 2]
+
+
+def test_dense_module_keys_equal_reference_modules():
+    """Key sets of the product's neck / head equal the reference's own modules' (golden state dicts)."""
+    import logging
+    from pillarnet_lts_amd import necks
+    from pillarnet_lts_amd.bbox_heads import CenterHead
+    g = np.load(os.path.join(G, "dense_neck.npz"))
+    log = logging.getLogger("t")
+    neck = necks.RPNV1(layer_nums=[2, 1], num_filters=24, in_channels=[16, 8], logger=log)
+    want = {k[len("rpnv1.sd."):]: g[k].shape for k in g.files if k.startswith("rpnv1.sd.")}
+    assert {k: tuple(v.shape) for k, v in neck.state_dict().items()} == {k: tuple(s) for k, s in want.items()}
+    ng = necks.RPNG(layer_nums=[1, 2], in_channels=[16, 8, 8], num_filters=[12, 8], logger=log)
+    want = {k[len("rpng.sd."):]: g[k].shape for k in g.files if k.startswith("rpng.sd.")}
+    assert {k: tuple(v.shape) for k, v in ng.state_dict().items()} == {k: tuple(s) for k, s in want.items()}
+    h = np.load(os.path.join(G, "dense_head.npz"))
+    head = CenterHead(tasks=[P.ConfigDict(stride=8, class_names=["car"]), P.ConfigDict(stride=8, class_names=["bus", "trailer"])],
+                      in_channels=[24], code_weights=[1.0] * 10,
+                      common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                      share_channel=16, reg_iou="GIoU")
+    want = {k[3:]: h[k].shape for k in h.files if k.startswith("sd.")}
+    assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == {k: tuple(s) for k, s in want.items()}
+
+
+def test_set_by_task_cfg_matches_reference():
+    with open(os.path.join(G, "configs.json")) as f:
+        ref = json.load(f)
+    checked = 0
+    for name, entry in ref.items():
+        if entry["test_cfg_by_task"] is None:
+            continue
+        head = entry["model"]["bbox_head"]
+        ncls = [len(t["class_names"]) for t in head["tasks"]]
+        got = set_by_task_cfg(P.ConfigDict(json.loads(json.dumps(entry["test_cfg"]))), ncls)
+        assert json.loads(json.dumps(got)) == entry["test_cfg_by_task"], name
+        checked += 1
+    assert checked >= 7
+
+
+def test_presets_equal_reference_configs():
+    with open(os.path.join(G, "configs.json")) as f:
+        ref = json.load(f)
+    def strip(d):
+        d = json.loads(json.dumps(d, default=lambda o: None))
+        for part in ("neck", ):
+            d[part].pop("logger", None)
+        return d
+    got = strip(presets.nusc_pillarnet18().model)
+    assert got == ref["pillarnet/pillarnet_centerhead_nusc.py"]["model"]
+    assert json.loads(json.dumps(presets.nusc_pillarnet18().test_cfg)) == ref["pillarnet/pillarnet_centerhead_nusc.py"]["test_cfg"]
+    got = strip(presets.waymo_pillarnet34_fpn().model)
+    assert got == ref["pillarnet/pillarnet34_fpn_centerhead_waymo.py"]["model"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present")
+def test_reference_live_configs_load_and_build_unchanged():
+    built = 0
+    for fn in sorted(os.listdir(os.path.join(REF_CFG, "pillarnet"))):
+        if not fn.endswith(".py"):
+            continue
+        cfg = P.Config.fromfile(os.path.join(REF_CFG, "pillarnet", fn))
+        model = P.build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        assert type(model).__name__ == "PillarNet"
+        assert isinstance(model.test_cfg.nms.nms_pre_max_size, (int, list))
+        built += 1
+    assert built == 7
+
+
+def test_no_cpu_fallback():
+    """Operators refuse CPU tensors instead of silently computing elsewhere."""
+    w = torch.zeros(32, 7)
+    with pytest.raises(_lib.PillarnetHipError):
+        pillar_ops.pillarize([torch.zeros(10, 5)], w, torch.ones(32), torch.zeros(32), 0.075,
+                             [-54, -54, -5, 54, 54, 3])
+    conv = sparse_conv.SubMConv2d(32, 32, 3, padding=1).eval()
+    x = P.SparseConvTensor(torch.zeros(4, 32), torch.zeros(4, 3, dtype=torch.int32), (8, 8), 1)
+    with pytest.raises(_lib.PillarnetHipError):
+        conv(x)
+    from pillarnet_lts_amd import iou3d_nms
+    with pytest.raises(_lib.PillarnetHipError):
+        iou3d_nms.boxes_iou_bev(torch.zeros(2, 7), torch.zeros(2, 7))
+    with pytest.raises(NotImplementedError):
+        sparse_conv.SubMConv2d(32, 32, 3, padding=1).train()(x)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PillarnetHipError, match="no CPU fallback"):
+        _lib.lib()
