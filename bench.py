@@ -42,7 +42,7 @@ def cpu_baseline(model, cfg):
     from oracle import detector_oracle as do
     from pillarnet_lts_amd import presets, synth
     from pillarnet_lts_amd.center_utils import set_by_task_cfg
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     test_cfg = set_by_task_cfg(copy.deepcopy(presets.nusc_pillarnet18().test_cfg), model.bbox_head.num_classes)
