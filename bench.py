@@ -43,6 +43,7 @@ def cpu_baseline(model, cfg):
     from pillarnet_lts_amd import presets, synth
     from pillarnet_lts_amd.center_utils import set_by_task_cfg
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 32)   # torch-CPU conv stops scaling long before 256 threads
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     test_cfg = set_by_task_cfg(copy.deepcopy(presets.nusc_pillarnet18().test_cfg), model.bbox_head.num_classes)
