@@ -216,6 +216,24 @@ int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
                          int32_t* out_num, int32_t* status, void* workspace,
                          size_t workspace_bytes, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * LDS-tiled gather -> MFMA implicit GEMM, bf16 inputs / weights, fp32 accumulate:
+ *   out[out_rows ? out_rows[m] : m, 0:cout] =
+ *       act( (sum_{t < ntaps} W[t] . in[nbr[t*nbr_stride + m], :]) * scale + shift (+ residual[m, :]) )
+ * The engine behind pn_spconv_forward (bf16) and behind the dense 3x3 / stride-2 / transposed
+ * convolutions of conv5, the RPN necks and CenterHead when they run on channels-last rows
+ * (det3d/models/backbones/PillarResNet.py:111-117, det3d/models/necks/rpn.py:147-207,
+ * det3d/models/bbox_heads/center_head.py:14-51,101-127).
+ * in [*, cin] bf16 rows; nbr NULL = identity (ntaps must be 1); weight [ntaps, cout, cin] bf16;
+ * out rows have stride out_ld elements (write a channel slice of a wider buffer by offsetting
+ * `out`); out_fp32 != 0 stores fp32 instead of bf16; residual rows have stride res_ld.
+ * ------------------------------------------------------------------------ */
+int pn_gather_gemm(const void* in, int cin, const int32_t* nbr, int nbr_stride, int ntaps,
+                   const int32_t* count_dev, int rows, const void* weight, int cout,
+                   const float* scale, const float* shift, const void* residual,
+                   int res_ld, int relu, void* out, int out_ld, int out_fp32,
+                   const int32_t* out_rows, pnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

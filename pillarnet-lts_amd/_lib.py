@@ -79,6 +79,9 @@ SIGNATURES = {
     "pn_centerhead_detect": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int,
                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "pn_gather_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                               c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,263 @@
+// LDS-tiled gather -> MFMA implicit GEMM (bf16 in, fp32 accumulate) for gfx950.
+//
+//   out[m, n0:n0+BN] = epilogue( sum_{tap < ntaps} W[tap][n, :] . in[nbr[tap][m], :] )
+//
+// Serves the sparse backbone (rulebook from the occupancy index) and -- with a regular-grid
+// rulebook -- the dense 3x3 / transposed convs of conv5, the neck and the head, whose activations
+// already live as [pixels, channels] rows (channels-last).
+//
+// Structure (one workgroup = BM output sites x BN output channels, NWM x NWN wavefronts):
+//   * K is walked in stages of BK input channels of one tap.  Per stage the workgroup stages the
+//     BN x BK weight tile and the BM x BK *gathered* activation tile into LDS (16-B global loads
+//     into registers issued one stage ahead, written to the other LDS buffer after the MFMAs of
+//     the current stage: one barrier per stage).  Missing neighbours contribute zero rows.
+//   * LDS rows are BK bf16 (128 B for BK = 64).  The 16-B chunk index is XOR-swizzled with the
+//     row so that the four 16-lane groups of a ds_read_b128 each touch all 64 banks once.
+//   * MFMA v_mfma_f32_32x32x16_bf16 computes D^T: A = weight rows (32 output channels x 16 k),
+//     B = activation rows (16 k x 32 sites).  A lane then owns 4 x 4 consecutive channels of one
+//     site, so the epilogue (per-channel scale/shift = folded bias + eval BatchNorm, optional
+//     residual, ReLU) stores 8-B (bf16) / 16-B (fp32) pieces straight into row-major output,
+//     with a row stride and channel offset so "concat" never materialises.
+//   * Weights are re-read from L2 once per workgroup, not once per wavefront as in the first
+//     kernel (spconv.hip), which was what bounded it at ~7 % of the MFMA peak.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int BK> __device__ __forceinline__ int swz(int row);
+template <> __device__ __forceinline__ int swz<64>(int row) { return (row >> 1) & 7; }  // 8 chunks / row
+template <> __device__ __forceinline__ int swz<32>(int row) { return (row >> 2) & 3; }  // 4 chunks / row
+
+template <typename TOut> struct OutOps;
+template <> struct OutOps<__bf16> {
+  static __device__ __forceinline__ void store4(__bf16* p, f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+};
+template <> struct OutOps<float> {
+  static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+
+struct GGArgs {
+  const __bf16* in;        // [*, cin] rows
+  const int32_t* nbr;      // [ntaps][nbr_stride] input row per (tap, output site) or -1; NULL: identity (ntaps == 1)
+  int nbr_stride;
+  const int32_t* count;    // device row count (NULL: rows)
+  int rows;                // capacity / host row count
+  const __bf16* wt;        // [ntaps][cout_total][cin]
+  int cin, cout_total, ntaps;
+  const float* scale;      // [cout_total]
+  const float* shift;
+  const __bf16* residual;  // [rows, res_ld] or NULL
+  int res_ld;
+  int relu;
+  void* out;               // [*, out_ld] rows, channel offset already applied by the caller
+  int out_ld;
+  const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
+};
+
+template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
+__global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
+  constexpr int NT = NWM * NWN * 64;
+  constexpr int CH = BK / 8;                 // 16-B chunks per LDS row
+  constexpr int WTM = BM / NWM, WTN = BN / NWN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ROWB = BK * 2;               // bytes per LDS row
+  constexpr int TILE_CHUNKS = (BM + BN) * CH;
+  constexpr int NLD = (TILE_CHUNKS + NT - 1) / NT;
+  constexpr int BUF_BYTES = (BM + BN) * ROWB;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int M = a.count ? *a.count : a.rows;
+  if (M > a.rows) M = a.rows;
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= M) return;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int kchunks = a.cin / BK;            // stages per tap
+  const int stages = a.ntaps * kchunks;
+
+  // ---- this thread's share of a stage: which (row, chunk) pieces it moves -----------------------
+  int ld_row[NLD], ld_chunk[NLD];
+  bool ld_act[NLD], ld_ok[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int q = tid + j * NT;
+    ld_ok[j] = q < TILE_CHUNKS;
+    ld_act[j] = q < BM * CH;
+    const int qq = ld_act[j] ? q : q - BM * CH;
+    ld_row[j] = qq / CH;
+    ld_chunk[j] = qq % CH;
+  }
+  uint4 regs[NLD];
+
+  auto issue = [&](int s) {
+    const int tap = s / kchunks, kc = s - tap * kchunks;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ld_ok[j]) {
+        if (ld_act[j]) {
+          const int m = m0 + ld_row[j];
+          int src = -1;
+          if (m < M) src = a.nbr ? a.nbr[(size_t)tap * a.nbr_stride + m] : m;
+          if (src >= 0)
+            v = *reinterpret_cast<const uint4*>(a.in + (size_t)src * a.cin + kc * BK + ld_chunk[j] * 8);
+        } else {
+          const int n = n0 + ld_row[j];
+          if (n < a.cout_total)
+            v = *reinterpret_cast<const uint4*>(a.wt + ((size_t)tap * a.cout_total + n) * a.cin + kc * BK +
+                                                ld_chunk[j] * 8);
+        }
+      }
+      regs[j] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      if (!ld_ok[j]) continue;
+      const int row = ld_row[j];
+      char* dst = base + (ld_act[j] ? 0 : BM * ROWB) + row * ROWB + ((ld_chunk[j] ^ swz<BK>(row)) << 4);
+      *reinterpret_cast<uint4*>(dst) = regs[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  for (int s = 0; s < stages; ++s) {
+    if (s + 1 < stages) issue(s + 1);
+    const char* abase = smem + (s & 1) * BUF_BYTES;
+    const char* wbase = abase + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fw[TN];
+      const int chunk = 2 * ks + lh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        fa[i] = *reinterpret_cast<const bf16x8*>(abase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + lr;
+        fw[j] = *reinterpret_cast<const bf16x8*>(wbase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < stages) commit((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D row = output channel (reg&3) + 8*(reg>>2) + 4*lh, D col = site lr -------------
+  TOut* out = reinterpret_cast<TOut*>(a.out);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + lr;
+    if (m >= M) continue;
+    const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;
+        if (c >= a.cout_total) continue;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+        v = v * sc + sh;
+        if (a.residual) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + c);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        OutOps<TOut>::store4(out + orow * a.out_ld + c, v);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
+static int launch_gg(const GGArgs& a, hipStream_t stream) {
+  constexpr int NT = NWM * NWN * 64;
+  constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2;
+  auto kern = gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut>;
+  static bool attr_set = false;
+  if (!attr_set && LDS > 32 * 1024) {
+    PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_set = true;
+  }
+  const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, stream, a);
+  PN_CHECK_LAUNCH("gather_gemm_kernel");
+  return PN_OK;
+}
+
+template <typename TOut>
+static int dispatch_gg(const GGArgs& a, hipStream_t stream) {
+  const int N = a.cout_total, rows = a.rows;
+  if (a.cin % 64 != 0) {  // 32 input channels: one 32-wide stage per tap
+    if (N <= 32) return launch_gg<128, 32, 4, 1, 32, TOut>(a, stream);
+    return launch_gg<128, 64, 2, 2, 32, TOut>(a, stream);
+  }
+  if (N <= 32) return launch_gg<128, 32, 4, 1, 64, TOut>(a, stream);
+  if (N <= 64) return launch_gg<128, 64, 2, 2, 64, TOut>(a, stream);
+  if (N <= 128) return launch_gg<128, 128, 2, 2, 64, TOut>(a, stream);
+  // wide outputs: one 128 x 256 tile per workgroup when that still fills the chip, else split
+  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut>(a, stream);
+  if (rows >= 64 * 96 * 2) return launch_gg<128, 128, 2, 2, 64, TOut>(a, stream);
+  return launch_gg<64, 128, 2, 2, 64, TOut>(a, stream);
+}
+
+extern "C" int pn_gather_gemm(const void* in, int cin, const int32_t* nbr, int nbr_stride, int ntaps,
+                              const int32_t* count_dev, int rows, const void* weight, int cout,
+                              const float* scale, const float* shift, const void* residual,
+                              int res_ld, int relu, void* out, int out_ld, int out_fp32,
+                              const int32_t* out_rows, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(in && weight && scale && shift && out, "pn_gather_gemm: null argument");
+  PN_CHECK_ARG(rows >= 1 && ntaps >= 1 && (nbr || ntaps == 1), "pn_gather_gemm: bad rows / taps");
+  PN_CHECK_ARG(cin % 32 == 0 && cout % 4 == 0, "pn_gather_gemm: cin %d must be a multiple of 32, cout %d of 4",
+               cin, cout);
+  PN_CHECK_ARG(!nbr || nbr_stride >= rows, "pn_gather_gemm: rulebook stride %d < rows %d", nbr_stride, rows);
+  PN_CHECK_ARG(out_ld % 4 == 0 && (!residual || res_ld % 4 == 0), "pn_gather_gemm: row strides must be multiples of 4");
+  PN_CHECK_ARG((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0 &&
+                   ((uintptr_t)out & 7) == 0 && ((uintptr_t)residual & 7) == 0,
+               "pn_gather_gemm: misaligned pointer");
+  GGArgs a;
+  a.in = (const __bf16*)in; a.nbr = nbr; a.nbr_stride = nbr_stride; a.count = count_dev; a.rows = rows;
+  a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
+  a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
+  a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
+  return out_fp32 ? dispatch_gg<float>(a, stream) : dispatch_gg<__bf16>(a, stream);
+}
