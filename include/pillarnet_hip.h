@@ -156,10 +156,11 @@ int pn_spconv_forward(int dtype, const void* in, int cin, const int32_t* nbr,
                       const void* residual, int relu, void* out, int cout, pnStream stream);
 
 /* SparseConvTensor.dense(): zero-fills out and writes the active rows;
- * channels_last != 0 -> [B,H,W,C] memory, else [B,C,H,W]. */
+ * channels_last != 0 -> [B,H,W,out_ld] memory of which the first C channels are written (out_ld = 0
+ * means C; a wider stride lets the rows land inside a concat buffer), else [B,C,H,W]. */
 int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* indices,
                        const int32_t* count_dev, int cap, int batch, int H, int W, int C,
-                       int channels_last, void* out, pnStream stream);
+                       int channels_last, int out_ld, void* out, pnStream stream);
 
 /* Occupancy index (bit per cell + per-word rank) of an existing sparse tensor's (b,y,x) rows --
  * what `spconv.SparseConvTensor(features, indices, spatial_shape, batch)`
@@ -191,6 +192,7 @@ int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, 
 typedef struct {
   const float* maps;
   int32_t height, width, channels, num_classes;
+  int32_t row_stride;      /* floats between consecutive cells of `maps` (0: = channels) */
   int32_t has_vel, has_iou;
   int32_t class_filter;    /* -1: all classes compete (rotate_nms_pcdet); k: only label k */
   int32_t label_offset;    /* center_head.py:337-343 */
@@ -224,11 +226,12 @@ int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
  * convolutions of conv5, the RPN necks and CenterHead when they run on channels-last rows
  * (det3d/models/backbones/PillarResNet.py:111-117, det3d/models/necks/rpn.py:147-207,
  * det3d/models/bbox_heads/center_head.py:14-51,101-127).
- * in [*, cin] bf16 rows; nbr NULL = identity (ntaps must be 1); weight [ntaps, cout, cin] bf16;
+ * in [*, in_ld] bf16 rows of which the first cin channels are read (in_ld = 0: cin; offset `in`
+ * to read a channel slice); nbr NULL = identity (ntaps must be 1); weight [ntaps, cout, cin] bf16;
  * out rows have stride out_ld elements (write a channel slice of a wider buffer by offsetting
  * `out`); out_fp32 != 0 stores fp32 instead of bf16; residual rows have stride res_ld.
  * ------------------------------------------------------------------------ */
-int pn_gather_gemm(const void* in, int cin, const int32_t* nbr, int nbr_stride, int ntaps,
+int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t* nbr, int nbr_stride, int ntaps,
                    const int32_t* count_dev, int rows, const void* weight, int cout,
                    const float* scale, const float* shift, const void* residual,
                    int res_ld, int relu, void* out, int out_ld, int out_fp32,

@@ -31,7 +31,7 @@ class pnPillarGrid(ctypes.Structure):
 class pnDecodeGroup(ctypes.Structure):
     _fields_ = [
         ("maps", c_void_p), ("height", c_int32), ("width", c_int32), ("channels", c_int32),
-        ("num_classes", c_int32), ("has_vel", c_int32), ("has_iou", c_int32),
+        ("num_classes", c_int32), ("row_stride", c_int32), ("has_vel", c_int32), ("has_iou", c_int32),
         ("class_filter", c_int32), ("label_offset", c_int32), ("stride", c_int32),
         ("score_threshold", c_float), ("rectifier", c_float), ("use_rectify", c_int32),
         ("nms_threshold", c_float), ("pre_max", c_int32), ("post_max", c_int32),
@@ -71,7 +71,7 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p]),
     "pn_sparse_to_dense": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_void_p, c_void_p]),
+                                   c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_occupancy_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pn_occupancy_from_indices": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -79,7 +79,7 @@ SIGNATURES = {
     "pn_centerhead_detect": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int,
                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
-    "pn_gather_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+    "pn_gather_gemm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                c_void_p, c_void_p]),
 }

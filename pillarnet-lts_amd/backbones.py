@@ -6,6 +6,7 @@ Module tree and parameter names are the reference's (`conv1.0.conv0.0.weight`, `
 mode every `conv -> BatchNorm1d [-> ReLU]` and every block tail `conv -> BN -> + identity -> ReLU`
 is one launch of the HIP implicit-GEMM kernel with the norm folded into the epilogue.
 """
+import torch
 import torch.nn as nn
 
 from .nn_utils import build_norm_layer
@@ -114,6 +115,15 @@ class _PillarResNet(nn.Module):
             x = getattr(self, f"conv{stage}")(x)
             feats[f"conv{stage}"] = x
         if self.DENSE_TAIL:
+            if getattr(self, "_dense_hip", False) and x.features_cap.dtype == torch.bfloat16:
+                from . import dense_hip
+                # the rows land in the first C channels of a 2C-wide buffer: RPNV1 / RPNG put the
+                # upsampled conv5 path right behind them, so the later concat needs no copy
+                dense4 = x.dense(out_channels=2 * x.features_cap.shape[1])
+                plan = dense_hip.PLANS.get(self.conv5, dense_hip.compile_stack)
+                feats["conv4"] = dense4
+                feats["conv5"] = dense_hip.run_stack(plan, dense_hip.Rows.from_nchw(dense4)).nchw()
+                return feats
             dense4 = x.dense()
             p = next(self.conv5.parameters())
             if dense4.dtype != p.dtype:

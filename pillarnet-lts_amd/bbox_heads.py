@@ -64,6 +64,14 @@ class SepHead(nn.Module):
 _ORDER = ("reg", "height", "dim", "rot", "vel", "iou", "hm")
 
 
+class PackedPreds(dict):
+    """A task's head outputs as the usual {name: [B,c,H,W]} dict whose tensors are channel views of
+    one packed fp32 map `packed` [B, H*W, ld] (channel order _ORDER) -- predict() reads that map
+    directly instead of concatenating."""
+    packed = None
+    channels = 0
+
+
 @HEADS.register_module
 class CenterHead(nn.Module):
     def __init__(self, tasks: List[dict], in_channels: List, code_weights: List, common_heads=dict(),
@@ -100,8 +108,31 @@ class CenterHead(nn.Module):
 
     def forward(self, x):
         assert len(x) == len(self.share_convs)
+        if getattr(self, "_dense_hip", False) and not self.training and x[0].dtype == torch.bfloat16:
+            return self._forward_hip(x)
         shared = [conv(x[k]) for k, conv in enumerate(self.share_convs)]
         return [head(shared[self.task_idx[k]]) for k, head in enumerate(self.task_heads)]
+
+    def _forward_hip(self, x):
+        """Shared conv, ALL first-layer towers of a level as one conv, one fp32-output conv per task
+        (block-diagonal weights): 2 + num_tasks launches instead of 73 convs + BN + ReLU passes."""
+        from . import dense_hip
+        plan = dense_hip.PLANS.get(self, dense_hip.HeadPlan)
+        outs = plan.run([dense_hip.Rows.from_nchw(f) for f in x])
+        preds = []
+        for t, (m, nout, npad, B, H, W) in enumerate(outs):
+            th = self.task_heads[t]
+            d = PackedPreds()
+            d.packed, d.channels = m.view(B, H * W, npad), nout
+            c = 0
+            img = m.view(B, H, W, npad)
+            for name in _ORDER:
+                if name in th.heads:
+                    k = th.heads[name][0]
+                    d[name] = img[..., c:c + k].permute(0, 3, 1, 2)
+                    c += k
+            preds.append(d)
+        return preds
 
     def loss(self, example, preds_dicts, train_cfg, **kwargs):
         from .losses import center_head_loss
@@ -137,16 +168,21 @@ class CenterHead(nn.Module):
         label_offset, out_cap = 0, 0
         for t, pd in enumerate(preds_dicts):
             has_iou = int("iou" in pd)
-            # one [B, H*W, C] fp32 map per task (tiny: C ~ 12 channels at head resolution)
-            parts = [pd[k] for k in _ORDER if k in pd]
-            m = torch.cat([p.float() for p in parts], dim=1).permute(0, 2, 3, 1).contiguous()
+            H, W = pd["hm"].shape[2], pd["hm"].shape[3]
+            if isinstance(pd, PackedPreds) and pd.packed is not None:
+                m, CH, LD = pd.packed, pd.channels, pd.packed.shape[2]
+            else:
+                # one [B, H*W, C] fp32 map per task (tiny: C ~ 12 channels at head resolution)
+                parts = [pd[k] for k in _ORDER if k in pd]
+                m = torch.cat([p.float() for p in parts], dim=1).permute(0, 2, 3, 1).contiguous()
+                CH = LD = m.shape[3]
             keep_alive.append(m)
-            H, W, CH = m.shape[1], m.shape[2], m.shape[3]
             classes = range(self.num_classes[t]) if multi_class else [None]
             for k in classes:
                 g = _lib.pnDecodeGroup()
                 g.maps = m.data_ptr()
                 g.height, g.width, g.channels, g.num_classes = H, W, CH, self.num_classes[t]
+                g.row_stride = LD
                 g.has_vel, g.has_iou = has_vel, has_iou
                 g.class_filter = -1 if k is None else k
                 g.label_offset = label_offset

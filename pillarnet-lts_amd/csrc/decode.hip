@@ -26,7 +26,7 @@ static constexpr int SEL_THREADS = 1024;
 
 struct DecodeSetDev {
   const float* maps;     // [B, H*W, CH]
-  int H, W, CH, ncls, has_vel, has_iou, class_filter, label_offset, stride;
+  int H, W, CH, LD, ncls, has_vel, has_iou, class_filter, label_offset, stride;
   float score_thr, rectifier, nms_thr;
   int use_rectify, pre_max, post_max;
   long long key_offset;  // start of this set-group's keys in the key scratch (per sample: + b*H*W)
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void decode_score_kernel(DecodeGroups G, Decod
   for (int i = threadIdx.x; i < DEC_BINS; i += 256) lhist[i] = 0u;
   __syncthreads();
   for (int cell = blockIdx.x * 256 + threadIdx.x; cell < cells; cell += gridDim.x * 256) {
-    const float* m = S.maps + ((size_t)b * cells + cell) * S.CH;
+    const float* m = S.maps + ((size_t)b * cells + cell) * S.LD;
     const int hm0 = ch_hm(S);
     float best = sigmoidf_ref(m[hm0]);
     int label = 0;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
   for (int i = tid; i < m; i += SEL_THREADS) {
     const unsigned long long e = list[i];
     const int cell = (int)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull));
-    const float* mp = S.maps + ((size_t)b * cells + cell) * S.CH;
+    const float* mp = S.maps + ((size_t)b * cells + cell) * S.LD;
     const int yy = cell / S.W, xx = cell - yy * S.W;
     const float x = centre_coord(xx, mp[0], S.stride, C.pillar_size, C.x_min);
     const float y = centre_coord(yy, mp[1], S.stride, C.pillar_size, C.y_min);
@@ -363,11 +363,13 @@ extern "C" int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
   for (int g = 0; g < num_groups; ++g) {
     const pnDecodeGroup& s = groups[g];
     PN_CHECK_ARG(s.maps && s.height > 0 && s.width > 0 && s.num_classes >= 1 &&
-                     s.channels == 8 + 2 * s.has_vel + s.has_iou + s.num_classes,
+                     s.channels == 8 + 2 * s.has_vel + s.has_iou + s.num_classes &&
+                     (s.row_stride == 0 || s.row_stride >= s.channels),
                  "pn_centerhead_detect: group %d channel layout mismatch", g);
     PN_CHECK_ARG(s.pre_max >= 1 && s.post_max >= 1, "pn_centerhead_detect: group %d bad pre/post", g);
     DecodeSetDev& d = G.g[g];
     d.maps = s.maps; d.H = s.height; d.W = s.width; d.CH = s.channels; d.ncls = s.num_classes;
+    d.LD = s.row_stride > 0 ? s.row_stride : s.channels;
     d.has_vel = s.has_vel; d.has_iou = s.has_iou; d.class_filter = s.class_filter;
     d.label_offset = s.label_offset; d.stride = s.stride; d.score_thr = s.score_threshold;
     d.rectifier = s.rectifier; d.nms_thr = s.nms_threshold; d.use_rectify = s.use_rectify;

@@ -45,7 +45,8 @@ template <> struct OutOps<float> {
 };
 
 struct GGArgs {
-  const __bf16* in;        // [*, cin] rows
+  const __bf16* in;        // [*, in_ld] rows, the first cin channels are used
+  int in_ld;
   const int32_t* nbr;      // [ntaps][nbr_stride] input row per (tap, output site) or -1; NULL: identity (ntaps == 1)
   int nbr_stride;
   const int32_t* count;    // device row count (NULL: rows)
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
           int src = -1;
           if (m < M) src = a.nbr ? a.nbr[(size_t)tap * a.nbr_stride + m] : m;
           if (src >= 0)
-            v = *reinterpret_cast<const uint4*>(a.in + (size_t)src * a.cin + kc * BK + ld_chunk[j] * 8);
+            v = *reinterpret_cast<const uint4*>(a.in + (size_t)src * a.in_ld + kc * BK + ld_chunk[j] * 8);
         } else {
           const int n = n0 + ld_row[j];
           if (n < a.cout_total)
@@ -239,7 +240,7 @@ static int dispatch_gg(const GGArgs& a, hipStream_t stream) {
   return launch_gg<64, 128, 2, 2, 64, TOut>(a, stream);
 }
 
-extern "C" int pn_gather_gemm(const void* in, int cin, const int32_t* nbr, int nbr_stride, int ntaps,
+extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t* nbr, int nbr_stride, int ntaps,
                               const int32_t* count_dev, int rows, const void* weight, int cout,
                               const float* scale, const float* shift, const void* residual,
                               int res_ld, int relu, void* out, int out_ld, int out_fp32,
@@ -247,6 +248,8 @@ extern "C" int pn_gather_gemm(const void* in, int cin, const int32_t* nbr, int n
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(in && weight && scale && shift && out, "pn_gather_gemm: null argument");
   PN_CHECK_ARG(rows >= 1 && ntaps >= 1 && (nbr || ntaps == 1), "pn_gather_gemm: bad rows / taps");
+  if (in_ld <= 0) in_ld = cin;
+  PN_CHECK_ARG(in_ld >= cin && in_ld % 8 == 0, "pn_gather_gemm: in_ld %d (cin %d)", in_ld, cin);
   PN_CHECK_ARG(cin % 32 == 0 && cout % 4 == 0, "pn_gather_gemm: cin %d must be a multiple of 32, cout %d of 4",
                cin, cout);
   PN_CHECK_ARG(!nbr || nbr_stride >= rows, "pn_gather_gemm: rulebook stride %d < rows %d", nbr_stride, rows);
@@ -255,7 +258,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, const int32_t* nbr, int n
                    ((uintptr_t)out & 7) == 0 && ((uintptr_t)residual & 7) == 0,
                "pn_gather_gemm: misaligned pointer");
   GGArgs a;
-  a.in = (const __bf16*)in; a.nbr = nbr; a.nbr_stride = nbr_stride; a.count = count_dev; a.rows = rows;
+  a.in = (const __bf16*)in; a.in_ld = in_ld; a.nbr = nbr; a.nbr_stride = nbr_stride; a.count = count_dev; a.rows = rows;
   a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;

@@ -308,7 +308,7 @@ extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, const int32
                  (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
                "pn_spconv_forward: pointers must be 16-B aligned");
   if (dtype == PN_DTYPE_BF16 && !getenv("PN_SPCONV_V1"))  // LDS-tiled kernel (gather_gemm.hip)
-    return pn_gather_gemm(in, cin, nbr, nbr_stride, 9, count_dev, cap, weight, cout, scale, shift, residual,
+    return pn_gather_gemm(in, cin, cin, nbr, nbr_stride, 9, count_dev, cap, weight, cout, scale, shift, residual,
                           cout, relu, out, cout, 0, nullptr, stream_);
   PN_CONV_CASE(32, 32, 4)
   PN_CONV_CASE(32, 64, 4)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void to_dense_kernel(const T* __restrict__ fea
                                                        const int32_t* __restrict__ indices,
                                                        const int32_t* __restrict__ count, int cap,
                                                        int H, int W, int C, int channels_last,
-                                                       T* __restrict__ out) {
+                                                       int out_ld, T* __restrict__ out) {
   int M = *count;
   if (M > cap) M = cap;
   if (channels_last) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void to_dense_kernel(const T* __restrict__ fea
       const int m = (int)(t / cpr), ch = (int)(t - (long long)m * cpr);
       const int b = indices[m * 3], y = indices[m * 3 + 1], x = indices[m * 3 + 2];
       const uint4 v = *reinterpret_cast<const uint4*>(feats + (size_t)m * C + ch * vec);
-      *reinterpret_cast<uint4*>(out + (((size_t)b * H + y) * W + x) * C + ch * vec) = v;
+      *reinterpret_cast<uint4*>(out + (((size_t)b * H + y) * W + x) * out_ld + ch * vec) = v;
     }
   } else {
     const long long total = (long long)M * C;
@@ -354,20 +354,27 @@ __global__ __launch_bounds__(256) void to_dense_kernel(const T* __restrict__ fea
 
 extern "C" int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* indices,
                                   const int32_t* count_dev, int cap, int batch, int H, int W, int C,
-                                  int channels_last, void* out, pnStream stream_) {
+                                  int channels_last, int out_ld, void* out, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(dtype == PN_DTYPE_F32 || dtype == PN_DTYPE_BF16, "pn_sparse_to_dense: dtype %d", dtype);
   PN_CHECK_ARG(feats && indices && count_dev && out && cap >= 1, "pn_sparse_to_dense: null argument");
   const size_t esz = dtype == PN_DTYPE_BF16 ? 2 : 4;
   PN_CHECK_ARG((C * esz) % 16 == 0, "pn_sparse_to_dense: row bytes must be a multiple of 16");
-  PN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)batch * H * W * C * esz, stream));
+  if (out_ld <= 0) out_ld = C;
+  PN_CHECK_ARG(out_ld >= C && (out_ld * esz) % 16 == 0 && (channels_last || out_ld == C),
+               "pn_sparse_to_dense: bad out_ld %d", out_ld);
+  if (out_ld == C) {
+    PN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)batch * H * W * C * esz, stream));
+  } else {
+    PN_CHECK_HIP(hipMemset2DAsync(out, (size_t)out_ld * esz, 0, (size_t)C * esz, (size_t)batch * H * W, stream));
+  }
   const int blocks = 2048;
   if (dtype == PN_DTYPE_BF16)
     hipLaunchKernelGGL(to_dense_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream,
-                       (const __bf16*)feats, indices, count_dev, cap, H, W, C, channels_last, (__bf16*)out);
+                       (const __bf16*)feats, indices, count_dev, cap, H, W, C, channels_last, out_ld, (__bf16*)out);
   else
     hipLaunchKernelGGL(to_dense_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)feats,
-                       indices, count_dev, cap, H, W, C, channels_last, (float*)out);
+                       indices, count_dev, cap, H, W, C, channels_last, out_ld, (float*)out);
   PN_CHECK_LAUNCH("to_dense_kernel");
   return PN_OK;
 }

@@ -53,17 +53,31 @@ class SingleStageDetector(BaseDetector):
         pass
 
     # -- MI355X inference set-up ----------------------------------------------------------------
-    def to_inference(self, dtype=torch.bfloat16, device="cuda"):
-        """eval mode; dense conv5 / neck / head cast to `dtype` in channels-last (MIOpen NHWC);
-        the sparse stages pick their dtype up from the feature rows.  fp32 keeps everything fp32."""
+    def to_inference(self, dtype=torch.bfloat16, device="cuda", dense_backend="hip"):
+        """eval mode for the MI355X inference path.
+
+        dtype bf16: sparse stages run bf16 MFMA with fp32 accumulation.  dense_backend "hip" runs
+        conv5 / neck / head through the same gather-GEMM kernel (plans compiled from the modules);
+        "miopen" keeps them on PyTorch-ROCm in bf16 channels-last.  dtype fp32 (the parity path)
+        always uses the torch modules for the dense part."""
+        assert dense_backend in ("hip", "miopen")
         self.eval().to(device)
         self.compute_dtype = dtype
+        use_hip = dense_backend == "hip" and dtype == torch.bfloat16
+        for m in (self.backbone, getattr(self, "neck", None), self.bbox_head):
+            if m is not None:
+                m._dense_hip = use_hip
         dense = [getattr(self.backbone, "conv5", None), getattr(self, "neck", None), self.bbox_head]
         for m in dense:
-            if m is not None:
+            if m is None:
+                continue
+            if use_hip or dtype == torch.float32:
+                m.float()          # plans convert weights themselves and fold BN from fp32 statistics
+            else:
                 m.to(dtype=dtype, memory_format=torch.channels_last)
-        for th in getattr(self.bbox_head, "task_heads", []):
-            th.keep_output_convs_fp32()
+        if not use_hip and dtype != torch.float32:
+            for th in getattr(self.bbox_head, "task_heads", []):
+                th.keep_output_convs_fp32()
         return self
 
 

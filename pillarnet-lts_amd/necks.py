@@ -58,6 +58,27 @@ class _NeckBase(nn.Module):
         ref = next(self.parameters())
         return [_dense(feats[n], ref) for n in names]
 
+    # ---- HIP dense path (bf16, eval): every conv is one gather-GEMM launch, concat is free --------
+    def _use_hip(self, x):
+        return getattr(self, "_dense_hip", False) and not self.training and x.dtype == torch.bfloat16
+
+    def _plan(self, name):
+        from . import dense_hip
+        return dense_hip.PLANS.get(getattr(self, name), dense_hip.compile_stack)
+
+    @staticmethod
+    def _concat_target(lateral, extra_channels):
+        """Rows view of [lateral | room for extra_channels]: in place when `lateral` already sits in
+        a wide enough buffer (SparseConvTensor.dense(out_channels=...)), else one copy."""
+        from . import dense_hip
+        r = dense_hip.Rows.from_nchw(lateral)
+        C = r.t.shape[1]
+        if r.ld >= C + extra_channels:
+            return r.widen(C + extra_channels), C
+        buf = torch.empty((r.t.shape[0], C + extra_channels), dtype=r.t.dtype, device=r.t.device)
+        buf[:, :C].copy_(r.t)
+        return dense_hip.Rows(buf, r.B, r.H, r.W), C
+
 
 @NECKS.register_module
 class RPNV1(_NeckBase):
@@ -73,6 +94,13 @@ class RPNV1(_NeckBase):
 
     def forward(self, pillar_features, **kwargs):
         c4, c5 = self._levels(pillar_features, ("conv4", "conv5"))
+        if self._use_hip(c4):
+            from . import dense_hip
+            x5 = dense_hip.run_stack(self._plan("block_5"), dense_hip.Rows.from_nchw(c5))
+            up = self._plan("deblock_5")
+            cat, C = self._concat_target(c4, up[-1].cout)
+            dense_hip.run_stack(up, x5, last_out=cat.t[:, C:])
+            return (dense_hip.run_stack(self._plan("block_4"), cat).nchw(),)
         x = torch.cat([c4, self.deblock_5(self.block_5(c5))], dim=1)
         return (self.block_4(x),)
 
@@ -111,6 +139,18 @@ class RPNG(_NeckBase):
 
     def forward(self, pillar_features, **kwargs):
         c3, c4, c5 = self._levels(pillar_features, ("conv3", "conv4", "conv5"))
+        if self._use_hip(c4):
+            from . import dense_hip
+            x5 = dense_hip.run_stack(self._plan("block_5"), dense_hip.Rows.from_nchw(c5))
+            up = self._plan("top_down_54")
+            cat4, C4 = self._concat_target(c4, up[-1].cout)
+            dense_hip.run_stack(up, x5, last_out=cat4.t[:, C4:])
+            x4 = dense_hip.run_stack(self._plan("block_4"), cat4)
+            up = self._plan("top_down_43")
+            cat3, C3 = self._concat_target(c3, up[-1].cout)
+            dense_hip.run_stack(up, x4, last_out=cat3.t[:, C3:])
+            x3 = dense_hip.run_stack(self._plan("block_3"), cat3)
+            return (x4.nchw(), x3.nchw())
         x4 = self.block_4(torch.cat([c4, self.top_down_54(self.block_5(c5))], dim=1))
         x3 = self.block_3(torch.cat([c3, self.top_down_43(x4)], dim=1))
         return (x4, x3)

@@ -247,17 +247,22 @@ class SparseSequential(SparseModule):
         return x
 
 
-def to_dense(x: SparseConvTensor, channels_last=True):
+def to_dense(x: SparseConvTensor, channels_last=True, out_channels=None):
+    """out_channels > C (channels-last only): the rows land in the first C channels of a
+    [B,H,W,out_channels] buffer (the rest is left for a later producer: concat without a copy);
+    the returned tensor is the [B,C,H,W] view of those channels."""
     feats = x.features_cap
     H, W = x.spatial_shape
     B, C = x.batch_size, feats.shape[1]
+    ld = C if out_channels is None else int(out_channels)
     if channels_last:
-        out = torch.empty((B, H, W, C), dtype=feats.dtype, device=feats.device)
+        out = torch.empty((B, H, W, ld), dtype=feats.dtype, device=feats.device)
     else:
+        assert ld == C
         out = torch.empty((B, C, H, W), dtype=feats.dtype, device=feats.device)
     rc = _lib.lib().pn_sparse_to_dense(_dtype_code(feats), _lib.ptr(feats), _lib.ptr(x.indices_cap),
                                        _lib.ptr(x.num_active), x.capacity, B, H, W, C,
-                                       int(channels_last), _lib.ptr(out),
+                                       int(channels_last), ld, _lib.ptr(out),
                                        _lib.current_stream(feats.device))
     _lib.check(rc, "pn_sparse_to_dense")
-    return out.permute(0, 3, 1, 2) if channels_last else out
+    return out[..., :C].permute(0, 3, 1, 2) if channels_last else out

@@ -97,9 +97,9 @@ class SparseConvTensor:
         out._n_host = self._n_host
         return out
 
-    def dense(self, channels_last=True):
+    def dense(self, channels_last=True, out_channels=None):
         """[B, C, H, W]; zero where inactive (spconv `.dense()`, PillarResNet.py:139).  The memory
         format is channels-last (each active row lands as one contiguous C-vector, and the MIOpen
         convs downstream want NHWC)."""
         from . import sparse_conv
-        return sparse_conv.to_dense(self, channels_last=channels_last)
+        return sparse_conv.to_dense(self, channels_last=channels_last, out_channels=out_channels)

@@ -47,5 +47,5 @@ def test_argument_validation_without_gpu():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.pnPillarGrid) == 12 * 4
-    assert ctypes.sizeof(_lib.pnDecodeGroup) == 8 + 15 * 4 + 4   # pointer + 15 x 4-byte fields, padded to 8
+    assert ctypes.sizeof(_lib.pnDecodeGroup) == 8 + 16 * 4       # pointer + 16 x 4-byte fields
     assert ctypes.sizeof(_lib.pnDecodeCommon) == 11 * 4
