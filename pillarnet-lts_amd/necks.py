@@ -55,7 +55,7 @@ class _NeckBase(nn.Module):
                 xavier_init(m, distribution="uniform")
 
     def _levels(self, feats, names):
-        ref = next(self.parameters())
+        ref = None if getattr(self, "_dense_hip", False) else next(self.parameters())
         return [_dense(feats[n], ref) for n in names]
 
     # ---- HIP dense path (bf16, eval): every conv is one gather-GEMM launch, concat is free --------
