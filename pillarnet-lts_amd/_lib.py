@@ -82,6 +82,11 @@ SIGNATURES = {
     "pn_gather_gemm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                c_void_p, c_void_p]),
+    "pn_gather_gemm_grouped": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                       c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                       c_void_p]),
+    "pn_tap_sum": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                           c_void_p, c_int, ctypes.c_longlong, c_void_p]),
 }
 
 _lib = None

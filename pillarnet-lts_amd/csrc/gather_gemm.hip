@@ -21,6 +21,7 @@
 //   * Weights are re-read from L2 once per workgroup, not once per wavefront as in the first
 //     kernel (spconv.hip), which was what bounded it at ~7 % of the MFMA peak.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -61,6 +62,8 @@ struct GGArgs {
   void* out;               // [*, out_ld] rows, channel offset already applied by the caller
   int out_ld;
   const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
+  // grouped launch (blockIdx.z = group g): element offsets added per group
+  long long g_in, g_wt, g_ss, g_out;
 };
 
 template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
@@ -75,7 +78,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   constexpr int BUF_BYTES = (BM + BN) * ROWB;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* nbr_lds = reinterpret_cast<int*>(smem + 2 * BUF_BYTES);   // [ntaps][BM] rulebook tile
 
+  {
+    const long long g = blockIdx.z;
+    a.in += g * a.g_in;
+    a.wt += g * a.g_wt;
+    a.scale += g * a.g_ss;
+    a.shift += g * a.g_ss;
+    a.out = reinterpret_cast<char*>(a.out) + g * a.g_out * (long long)sizeof(TOut);
+  }
   int M = a.count ? *a.count : a.rows;
   if (M > a.rows) M = a.rows;
   const int m0 = blockIdx.x * BM;
@@ -101,6 +113,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   }
   uint4 regs[NLD];
 
+  // the tile's rulebook goes to LDS once: the per-stage gather then costs one LDS read + one
+  // global load instead of two dependent global loads
+  for (int q = tid; q < a.ntaps * BM; q += NT) {
+    const int tap = q / BM, r = q - tap * BM, m = m0 + r;
+    int src = -1;
+    if (m < M) src = a.nbr ? a.nbr[(size_t)tap * a.nbr_stride + m] : m;
+    nbr_lds[q] = src;
+  }
+  __syncthreads();
+
   auto issue = [&](int s) {
     const int tap = s / kchunks, kc = s - tap * kchunks;
 #pragma unroll
@@ -108,9 +130,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (ld_ok[j]) {
         if (ld_act[j]) {
-          const int m = m0 + ld_row[j];
-          int src = -1;
-          if (m < M) src = a.nbr ? a.nbr[(size_t)tap * a.nbr_stride + m] : m;
+          const int src = nbr_lds[tap * BM + ld_row[j]];
           if (src >= 0)
             v = *reinterpret_cast<const uint4*>(a.in + (size_t)src * a.in_ld + kc * BK + ld_chunk[j] * 8);
         } else {
@@ -208,36 +228,48 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   }
 }
 
+static constexpr int GG_MAX_TAPS = 9;
+
 template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
-static int launch_gg(const GGArgs& a, hipStream_t stream) {
+static int launch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = NWM * NWN * 64;
-  constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2;
+  constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2 + (size_t)GG_MAX_TAPS * BM * 4;
   auto kern = gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut>;
   static bool attr_set = false;
   if (!attr_set && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_set = true;
   }
-  const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN));
+  const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN), groups);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, stream, a);
   PN_CHECK_LAUNCH("gather_gemm_kernel");
   return PN_OK;
 }
 
 template <typename TOut>
-static int dispatch_gg(const GGArgs& a, hipStream_t stream) {
+static int dispatch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   const int N = a.cout_total, rows = a.rows;
+  static const char* force = getenv("PN_GG_FORCE");   // tuning aid: A / B / E for wide outputs
   if (a.cin % 64 != 0) {  // 32 input channels: one 32-wide stage per tap
-    if (N <= 32) return launch_gg<128, 32, 4, 1, 32, TOut>(a, stream);
-    return launch_gg<128, 64, 2, 2, 32, TOut>(a, stream);
+    if (N <= 32) return launch_gg<128, 32, 4, 1, 32, TOut>(a, groups, stream);
+    return launch_gg<128, 64, 2, 2, 32, TOut>(a, groups, stream);
   }
-  if (N <= 32) return launch_gg<128, 32, 4, 1, 64, TOut>(a, stream);
-  if (N <= 64) return launch_gg<128, 64, 2, 2, 64, TOut>(a, stream);
-  if (N <= 128) return launch_gg<128, 128, 2, 2, 64, TOut>(a, stream);
+  if (N <= 32) return launch_gg<128, 32, 4, 1, 64, TOut>(a, groups, stream);
+  if (N <= 64) return launch_gg<128, 64, 2, 2, 64, TOut>(a, groups, stream);
+  if (force && N > 128) {
+    if (force[0] == 'A') return launch_gg<128, 256, 2, 4, 64, TOut>(a, groups, stream);
+    if (force[0] == 'B') return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
+    if (force[0] == 'E') return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
+    if (force[0] == 'F') return launch_gg<64, 256, 1, 4, 64, TOut>(a, groups, stream);
+  }
+  if (N <= 128) {
+    if (rows * (long long)groups >= 128 * 192) return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
+    return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
+  }
   // wide outputs: one 128 x 256 tile per workgroup when that still fills the chip, else split
-  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut>(a, stream);
-  if (rows >= 64 * 96 * 2) return launch_gg<128, 128, 2, 2, 64, TOut>(a, stream);
-  return launch_gg<64, 128, 2, 2, 64, TOut>(a, stream);
+  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut>(a, groups, stream);
+  if (rows >= 64 * 96 * 2) return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
+  return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
 }
 
 extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t* nbr, int nbr_stride, int ntaps,
@@ -262,5 +294,69 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t*
   a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
-  return out_fp32 ? dispatch_gg<float>(a, stream) : dispatch_gg<__bf16>(a, stream);
+  a.g_in = a.g_wt = a.g_ss = a.g_out = 0;
+  PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
+  return out_fp32 ? dispatch_gg<float>(a, 1, stream) : dispatch_gg<__bf16>(a, 1, stream);
+}
+
+// `groups` independent problems that share rows / rulebook and differ by a channel offset of the
+// input (group g reads in + g*in_group_cols), their own [ntaps, cout, cin] weights and scale/shift,
+// and write out + g*out_group_cols: the per-task convs of CenterHead in one launch.
+extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, int in_group_cols,
+                                      const int32_t* nbr, int nbr_stride, int ntaps, int rows,
+                                      const void* weight, int cout, int groups, const float* scale,
+                                      const float* shift, int relu, void* out, int out_ld,
+                                      int out_group_cols, int out_fp32, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(in && weight && scale && shift && out && groups >= 1 && rows >= 1,
+               "pn_gather_gemm_grouped: bad argument");
+  PN_CHECK_ARG(ntaps >= 1 && ntaps <= GG_MAX_TAPS && (nbr || ntaps == 1), "pn_gather_gemm_grouped: bad taps");
+  PN_CHECK_ARG(cin % 32 == 0 && cout % 4 == 0 && in_ld % 8 == 0 && in_group_cols % 8 == 0 && out_ld % 4 == 0 &&
+                   out_group_cols % 4 == 0,
+               "pn_gather_gemm_grouped: channel counts / strides not aligned");
+  GGArgs a;
+  a.in = (const __bf16*)in; a.in_ld = in_ld; a.nbr = nbr; a.nbr_stride = nbr_stride; a.count = nullptr;
+  a.rows = rows; a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
+  a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
+  a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;
+  a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
+  return out_fp32 ? dispatch_gg<float>(a, groups, stream) : dispatch_gg<__bf16>(a, groups, stream);
+}
+
+// out[p, c] = bias[c] + sum_tap z[nbr[tap][p], tap*C + c]   (fp32): the spatial half of a 3x3 conv
+// whose per-tap channel products were computed first as one 1x1 GEMM (z = x . [W_0 | ... | W_8]).
+__global__ __launch_bounds__(256) void tap_sum_kernel(const float* __restrict__ z, int z_ld,
+                                                      const int32_t* __restrict__ nbr, int nbr_stride,
+                                                      int rows, int C, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int out_ld,
+                                                      long long g_z, long long g_out, int g_bias) {
+  const int g = blockIdx.y;
+  z += g * g_z; out += g * g_out; bias += g * g_bias;
+  const int c4 = C / 4;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)rows * c4;
+       t += (long long)gridDim.x * 256) {
+    const int p = (int)(t / c4), c = (int)(t - (long long)p * c4) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int src = nbr[(size_t)tap * nbr_stride + p];
+      if (src >= 0) acc += *reinterpret_cast<const f32x4*>(z + (size_t)src * z_ld + tap * C + c);
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)p * out_ld + c) = acc;
+  }
+}
+
+extern "C" int pn_tap_sum(const float* z, int z_ld, long long z_group_stride, const int32_t* nbr,
+                          int nbr_stride, int rows, int channels, int groups, const float* bias,
+                          float* out, int out_ld, long long out_group_stride, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(z && nbr && bias && out && rows >= 1 && groups >= 1, "pn_tap_sum: null argument");
+  PN_CHECK_ARG(channels % 4 == 0 && z_ld % 4 == 0 && out_ld % 4 == 0 && z_ld >= 9 * channels,
+               "pn_tap_sum: channels / strides must be multiples of 4");
+  int bx = pn_div_up((long long)rows * (channels / 4), 256);
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(tap_sum_kernel, dim3(bx, groups), dim3(256), 0, stream, z, z_ld, nbr, nbr_stride, rows,
+                     channels, bias, out, out_ld, z_group_stride, out_group_stride, channels);
+  PN_CHECK_LAUNCH("tap_sum_kernel");
+  return PN_OK;
 }
