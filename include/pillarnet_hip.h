@@ -147,10 +147,11 @@ int pn_spconv_down_rules(const int32_t* in_indices, const int32_t* in_count_dev,
                          void* scratch, size_t scratch_bytes, pnStream stream);
 
 /* out[m, :] = act( (sum_k W[k] . in[nbr[k][m], :]) * scale + shift (+ residual[m, :]) )
- * in [*, cin], out/residual [cap, cout] of `dtype`; weight [9, cout, cin] of `dtype`
+ * in [in_rows, cin] (in_rows = rows allocated, bounds the LDS-DMA descriptor; 0 = unknown),
+ * out/residual [cap, cout] of `dtype`; weight [9, cout, cin] of `dtype`
  * (spconv 2.x stores [cout, 3, 3, cin]); scale/shift fp32 [cout] (conv bias and eval-mode
  * BatchNorm1d folded; base.py:154-170); relu != 0 applies max(.,0).  fp32 accumulation. */
-int pn_spconv_forward(int dtype, const void* in, int cin, const int32_t* nbr,
+int pn_spconv_forward(int dtype, const void* in, int cin, long long in_rows, const int32_t* nbr,
                       int nbr_stride, const int32_t* count_dev, int cap,
                       const void* weight, const float* scale, const float* shift,
                       const void* residual, int relu, void* out, int cout, pnStream stream);
@@ -227,11 +228,12 @@ int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
  * (det3d/models/backbones/PillarResNet.py:111-117, det3d/models/necks/rpn.py:147-207,
  * det3d/models/bbox_heads/center_head.py:14-51,101-127).
  * in [*, in_ld] bf16 rows of which the first cin channels are read (in_ld = 0: cin; offset `in`
- * to read a channel slice); nbr NULL = identity (ntaps must be 1); weight [ntaps, cout, cin] bf16;
+ * to read a channel slice); in_rows = rows allocated behind `in` (bounds the buffer descriptor of
+ * the LDS-DMA staging path; 0 selects register staging); nbr NULL = identity (ntaps must be 1); weight [ntaps, cout, cin] bf16;
  * out rows have stride out_ld elements (write a channel slice of a wider buffer by offsetting
  * `out`); out_fp32 != 0 stores fp32 instead of bf16; residual rows have stride res_ld.
  * ------------------------------------------------------------------------ */
-int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t* nbr, int nbr_stride, int ntaps,
+int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_rows, const int32_t* nbr, int nbr_stride, int ntaps,
                    const int32_t* count_dev, int rows, const void* weight, int cout,
                    const float* scale, const float* shift, const void* residual,
                    int res_ld, int relu, void* out, int out_ld, int out_fp32,
@@ -241,7 +243,7 @@ int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t* nbr, int n
  * channel slice starting at in + g*in_group_cols, uses weight + g*ntaps*cout*cin and
  * scale/shift + g*cout, and writes out + g*out_group_cols.  (CenterHead's per-task output convs,
  * det3d/models/bbox_heads/center_head.py:31-32,101-112, in one launch.) */
-int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, int in_group_cols,
+int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows, int in_group_cols,
                            const int32_t* nbr, int nbr_stride, int ntaps, int rows,
                            const void* weight, int cout, int groups, const float* scale,
                            const float* shift, int relu, void* out, int out_ld,

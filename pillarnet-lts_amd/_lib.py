@@ -67,7 +67,7 @@ SIGNATURES = {
                                      c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
-    "pn_spconv_forward": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+    "pn_spconv_forward": (c_int, [c_int, c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p]),
     "pn_sparse_to_dense": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -79,10 +79,10 @@ SIGNATURES = {
     "pn_centerhead_detect": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int,
                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
-    "pn_gather_gemm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+    "pn_gather_gemm": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                c_void_p, c_void_p]),
-    "pn_gather_gemm_grouped": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+    "pn_gather_gemm_grouped": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p]),
     "pn_tap_sum": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

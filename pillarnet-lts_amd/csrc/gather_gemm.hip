@@ -48,6 +48,7 @@ template <> struct OutOps<float> {
 struct GGArgs {
   const __bf16* in;        // [*, in_ld] rows, the first cin channels are used
   int in_ld;
+  unsigned in_bytes;       // extent of `in` for the buffer descriptor of the LDS-DMA path (0: use register staging)
   const int32_t* nbr;      // [ntaps][nbr_stride] input row per (tap, output site) or -1; NULL: identity (ntaps == 1)
   int nbr_stride;
   const int32_t* count;    // device row count (NULL: rows)
@@ -66,7 +67,11 @@ struct GGArgs {
   long long g_in, g_wt, g_ss, g_out;
 };
 
-template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
+// out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
+// missing neighbour (or a weight row past cout) becomes a zero LDS row on the LDS-DMA path
+static constexpr unsigned GG_OOB = 0x80000000u;
+
+template <int BM, int BN, int NWM, int NWN, int BK, typename TOut, bool DMA>
 __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   constexpr int NT = NWM * NWN * 64;
   constexpr int CH = BK / 8;                 // 16-B chunks per LDS row
@@ -123,6 +128,45 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   }
   __syncthreads();
 
+  // ---- LDS-DMA staging (buffer_load_dwordx4 ... lds): each wave-instruction lands 1 KiB = 8 LDS rows;
+  // lane l fills slot l%8 of row 8p + l/8, so it fetches chunk (slot ^ swizzle(row)) of that row's
+  // source -- the swizzle lives in the per-lane SOURCE address, the LDS image stays linear.
+  constexpr int PIECES = (BM + BN) / 8;            // per stage (rows are BK*2 = 8*16 B or 4*16 B)
+  constexpr int ROWS_PER_PIECE = 1024 / ROWB;      // 8 (BK 64) or 16 (BK 32)
+  constexpr int NPIECE = ((BM + BN) / ROWS_PER_PIECE + NT / 64 - 1) / (NT / 64);
+  __amdgpu_buffer_rsrc_t rs_in, rs_wt;
+  if constexpr (DMA) {
+    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, (int)((size_t)a.ntaps * a.cout_total * a.cin * 2), 0x00020000);
+  }
+  (void)PIECES;
+  auto issue_dma = [&](int s, int buf) {
+    const int tap = s / kchunks, kc = s - tap * kchunks;
+    char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int piece = wave + j * (NT / 64);       // wave-uniform
+      if (piece * ROWS_PER_PIECE >= BM + BN) break;
+      const int row = piece * ROWS_PER_PIECE + lane / CH;   // row inside [acts | weights]
+      const int slot = lane % CH;
+      auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+      if (row < BM) {
+        const int src = nbr_lds[tap * BM + row];
+        const unsigned off = src >= 0 ? (unsigned)src * (unsigned)(a.in_ld * 2) + (unsigned)(kc * ROWB) +
+                                            (unsigned)((slot ^ swz<BK>(row)) << 4)
+                                      : GG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, 0, 0, 0);
+      } else {
+        const int r = row - BM, n = n0 + r;
+        const unsigned off = n < a.cout_total
+                                 ? ((unsigned)(tap * a.cout_total + n) * (unsigned)a.cin) * 2u + (unsigned)(kc * ROWB) +
+                                       (unsigned)((slot ^ swz<BK>(r)) << 4)
+                                 : GG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, lds, 16, off, 0, 0, 0);
+      }
+    }
+  };
+
   auto issue = [&](int s) {
     const int tap = s / kchunks, kc = s - tap * kchunks;
 #pragma unroll
@@ -162,12 +206,20 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  issue(0);
-  commit(0);
+  if constexpr (DMA) {
+    issue_dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    issue(0);
+    commit(0);
+  }
   __syncthreads();
 
   for (int s = 0; s < stages; ++s) {
-    if (s + 1 < stages) issue(s + 1);
+    if (s + 1 < stages) {
+      if constexpr (DMA) issue_dma(s + 1, (s + 1) & 1);
+      else issue(s + 1);
+    }
     const char* abase = smem + (s & 1) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
 #pragma unroll
@@ -190,7 +242,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < stages) commit((s + 1) & 1);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (s + 1 < stages) commit((s + 1) & 1);
+    }
     __syncthreads();
   }
 
@@ -234,11 +290,14 @@ template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
 static int launch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = NWM * NWN * 64;
   constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2 + (size_t)GG_MAX_TAPS * BM * 4;
-  auto kern = gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut>;
-  static bool attr_set = false;
-  if (!attr_set && LDS > 32 * 1024) {
+  static const bool no_dma = getenv("PN_GG_NO_DMA") != nullptr;
+  const bool dma = a.in_bytes != 0 && !no_dma;
+  auto kern = dma ? gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, true>
+                  : gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[dma] && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_set = true;
+    attr_set[dma] = true;
   }
   const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN), groups);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, stream, a);
@@ -272,7 +331,12 @@ static int dispatch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
 }
 
-extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t* nbr, int nbr_stride, int ntaps,
+static unsigned gg_in_bytes(long long in_rows, int in_ld) {
+  const long long b = in_rows * (long long)in_ld * 2;
+  return (in_rows > 0 && b < (long long)GG_OOB) ? (unsigned)b : 0u;   // 0 -> register staging
+}
+
+extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_rows, const int32_t* nbr, int nbr_stride, int ntaps,
                               const int32_t* count_dev, int rows, const void* weight, int cout,
                               const float* scale, const float* shift, const void* residual,
                               int res_ld, int relu, void* out, int out_ld, int out_fp32,
@@ -290,7 +354,8 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t*
                    ((uintptr_t)out & 7) == 0 && ((uintptr_t)residual & 7) == 0,
                "pn_gather_gemm: misaligned pointer");
   GGArgs a;
-  a.in = (const __bf16*)in; a.in_ld = in_ld; a.nbr = nbr; a.nbr_stride = nbr_stride; a.count = count_dev; a.rows = rows;
+  a.in = (const __bf16*)in; a.in_ld = in_ld; a.in_bytes = gg_in_bytes(in_rows, in_ld); a.nbr = nbr;
+  a.nbr_stride = nbr_stride; a.count = count_dev; a.rows = rows;
   a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
@@ -302,7 +367,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, const int32_t*
 // `groups` independent problems that share rows / rulebook and differ by a channel offset of the
 // input (group g reads in + g*in_group_cols), their own [ntaps, cout, cin] weights and scale/shift,
 // and write out + g*out_group_cols: the per-task convs of CenterHead in one launch.
-extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, int in_group_cols,
+extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows, int in_group_cols,
                                       const int32_t* nbr, int nbr_stride, int ntaps, int rows,
                                       const void* weight, int cout, int groups, const float* scale,
                                       const float* shift, int relu, void* out, int out_ld,
@@ -315,7 +380,8 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, int in
                    out_group_cols % 4 == 0,
                "pn_gather_gemm_grouped: channel counts / strides not aligned");
   GGArgs a;
-  a.in = (const __bf16*)in; a.in_ld = in_ld; a.nbr = nbr; a.nbr_stride = nbr_stride; a.count = nullptr;
+  a.in = (const __bf16*)in; a.in_ld = in_ld; a.in_bytes = gg_in_bytes(in_rows, in_ld); a.nbr = nbr;
+  a.nbr_stride = nbr_stride; a.count = nullptr;
   a.rows = rows; a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;

@@ -295,7 +295,7 @@ static int launch_conv(const void* in, const int32_t* nbr, int nbr_stride, const
                                                  scale, shift, residual, relu, out, stream);        \
   }
 
-extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, const int32_t* nbr,
+extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, long long in_rows, const int32_t* nbr,
                                  int nbr_stride, const int32_t* count_dev, int cap,
                                  const void* weight, const float* scale, const float* shift,
                                  const void* residual, int relu, void* out, int cout,
@@ -308,7 +308,7 @@ extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, const int32
                  (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
                "pn_spconv_forward: pointers must be 16-B aligned");
   if (dtype == PN_DTYPE_BF16 && !getenv("PN_SPCONV_V1"))  // LDS-tiled kernel (gather_gemm.hip)
-    return pn_gather_gemm(in, cin, cin, nbr, nbr_stride, 9, count_dev, cap, weight, cout, scale, shift, residual,
+    return pn_gather_gemm(in, cin, cin, in_rows, nbr, nbr_stride, 9, count_dev, cap, weight, cout, scale, shift, residual,
                           cout, relu, out, cout, 0, nullptr, stream_);
   PN_CONV_CASE(32, 32, 4)
   PN_CONV_CASE(32, 64, 4)

@@ -100,7 +100,7 @@ class Rows:
 def _launch(x, cin, nbr, ntaps, rows, w, scale, shift, relu, out, out_ld, fp32_out=False, out_rows=None,
             residual=None, res_ld=0, in_ld=0):
     """x / out: 2-D views with unit channel stride (their data_ptr carries any channel offset)."""
-    rc = _lib.lib().pn_gather_gemm(_lib.ptr(x), cin, in_ld, _lib.ptr(nbr), 0 if nbr is None else nbr.shape[1], ntaps,
+    rc = _lib.lib().pn_gather_gemm(_lib.ptr(x), cin, in_ld, x.shape[0], _lib.ptr(nbr), 0 if nbr is None else nbr.shape[1], ntaps,
                                    None, rows, _lib.ptr(w), w.shape[1], _lib.ptr(scale), _lib.ptr(shift),
                                    _lib.ptr(residual), res_ld, int(relu), _lib.ptr(out), out_ld, int(fp32_out),
                                    _lib.ptr(out_rows), _lib.current_stream(x.device))
@@ -301,7 +301,7 @@ class HeadPlan:
                 kin, npad, wz, ones, zeros, bias, k0 = fused
                 G = len(task_convs)
                 z = torch.empty((rows, G * 9 * npad), dtype=torch.float32, device=dev)
-                rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, kin, None, 0, 1, rows,
+                rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, None, 0, 1, rows,
                                               _lib.ptr(wz), 9 * npad, G, _lib.ptr(ones), _lib.ptr(zeros), 0,
                                               _lib.ptr(z), G * 9 * npad, 9 * npad, 1, _lib.current_stream(dev))
                 _lib.check(rc, "pn_gather_gemm_grouped")

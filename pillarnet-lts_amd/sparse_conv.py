@@ -110,7 +110,7 @@ def _launch_conv(dt, feats, cin, nbr, stride, num, cap, w, scale, shift, res, re
     if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
-    rc = _lib.lib().pn_spconv_forward(dt, _lib.ptr(feats), cin, _lib.ptr(nbr), stride, _lib.ptr(num), cap,
+    rc = _lib.lib().pn_spconv_forward(dt, _lib.ptr(feats), cin, feats.shape[0], _lib.ptr(nbr), stride, _lib.ptr(num), cap,
                                       _lib.ptr(w), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
                                       int(relu), _lib.ptr(out), cout, _lib.current_stream(dev))
     if probe:

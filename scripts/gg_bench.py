@@ -29,7 +29,7 @@ def run(name, x, nbr, rows, count, cin, cout, iters=20, fp32_out=False):
     out = torch.empty((rows, cout), dtype=torch.float32 if fp32_out else torch.bfloat16, device=dev)
 
     def call():
-        rc = L.pn_gather_gemm(_lib.ptr(x), cin, cin, _lib.ptr(nbr), nbr.shape[1], 9, _lib.ptr(count), rows,
+        rc = L.pn_gather_gemm(_lib.ptr(x), cin, cin, x.shape[0], _lib.ptr(nbr), nbr.shape[1], 9, _lib.ptr(count), rows,
                               _lib.ptr(w), cout, _lib.ptr(scale), _lib.ptr(shift), None, 0, 1, _lib.ptr(out),
                               cout, int(fp32_out), None, _lib.current_stream(dev))
         _lib.check(rc, "gg")

@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"null" in L.pn_last_error()
     assert L.pn_nms_workspace_bytes(0, 10) == 0
     assert L.pn_nms_workspace_bytes(2, 1000) >= 2 * 1000 * 16 * 8
-    assert L.pn_spconv_forward(7, None, 32, None, 0, None, 0, None, None, None, None, 0, None, 32, None) == -1
+    assert L.pn_spconv_forward(7, None, 32, 0, None, 0, None, 0, None, None, None, None, 0, None, 32, None) == -1
 
 
 def test_struct_layouts_match_header():
