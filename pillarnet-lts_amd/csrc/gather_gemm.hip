@@ -98,7 +98,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   const int m0 = blockIdx.x * BM;
   if (m0 >= M) return;
   const int n0 = blockIdx.y * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave index as a scalar: keeps the LDS-DMA descriptor choice, M0 base and branches wave-uniform
+  // (otherwise hipcc wraps every buffer_load in a readfirstlane waterfall loop)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
   const int kchunks = a.cin / BK;            // stages per tap
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
       const int row = piece * ROWS_PER_PIECE + lane / CH;   // row inside [acts | weights]
       const int slot = lane % CH;
       auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
-      if (row < BM) {
+      if (piece * ROWS_PER_PIECE < BM) {   // wave-uniform: a piece never straddles the two tiles
         const int src = nbr_lds[tap * BM + row];
         const unsigned off = src >= 0 ? (unsigned)src * (unsigned)(a.in_ld * 2) + (unsigned)(kc * ROWB) +
                                             (unsigned)((slot ^ swz<BK>(row)) << 4)
