@@ -95,7 +95,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   }
   int M = a.count ? *a.count : a.rows;
   if (M > a.rows) M = a.rows;
-  const int m0 = blockIdx.x * BM;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB
+  // L2), so give every XCD one CONTIGUOUS band of row tiles.  Neighbouring tiles gather overlapping
+  // input rows (3x3 halo: ~3 image rows per 0.7-row tile); in a band they hit the same L2 instead of
+  // every L2 pulling the whole map.  Bijective for any grid size; affects speed only.
+  int bx = blockIdx.x;
+  {
+    const int nwg = gridDim.x, x = bx & 7, q = nwg >> 3, r = nwg & 7;
+    bx = x * q + (x < r ? x : r) + (bx >> 3);
+  }
+  const int m0 = bx * BM;
   if (m0 >= M) return;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
