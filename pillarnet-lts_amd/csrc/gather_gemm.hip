@@ -101,11 +101,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   // every L2 pulling the whole map.  Bijective for any grid size; affects speed only.
   int bx = blockIdx.x;
   {
-    const int nwg = gridDim.x, x = bx & 7, q = nwg >> 3, r = nwg & 7;
+    const int nwg = (M + BM - 1) / BM;   // tiles that hold rows (the grid covers the capacity)
+    if (bx >= nwg) return;
+    const int x = bx & 7, q = nwg >> 3, r = nwg & 7;
     bx = x * q + (x < r ? x : r) + (bx >> 3);
   }
   const int m0 = bx * BM;
-  if (m0 >= M) return;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as a scalar: keeps the LDS-DMA descriptor choice, M0 base and branches wave-uniform
