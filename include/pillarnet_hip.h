@@ -158,10 +158,13 @@ int pn_spconv_forward(int dtype, const void* in, int cin, long long in_rows, con
 
 /* SparseConvTensor.dense(): zero-fills out and writes the active rows;
  * channels_last != 0 -> [B,H,W,out_ld] memory of which the first C channels are written (out_ld = 0
- * means C; a wider stride lets the rows land inside a concat buffer), else [B,C,H,W]. */
+ * means C; a wider stride lets the rows land inside a concat buffer), else [B,C,H,W].
+ * occ_bits / occ_rank (optional, channels-last only): the tensor's occupancy index; with it every
+ * output cell is written once (row or zeros) and no memset pass is issued. */
 int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* indices,
                        const int32_t* count_dev, int cap, int batch, int H, int W, int C,
-                       int channels_last, int out_ld, void* out, pnStream stream);
+                       int channels_last, int out_ld, const uint64_t* occ_bits,
+                       const int32_t* occ_rank, void* out, pnStream stream);
 
 /* Occupancy index (bit per cell + per-word rank) of an existing sparse tensor's (b,y,x) rows --
  * what `spconv.SparseConvTensor(features, indices, spatial_shape, batch)`

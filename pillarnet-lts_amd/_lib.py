@@ -71,7 +71,7 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p]),
     "pn_sparse_to_dense": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_int, c_void_p, c_void_p]),
+                                   c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pn_occupancy_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pn_occupancy_from_indices": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

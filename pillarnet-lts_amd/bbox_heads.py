@@ -214,7 +214,7 @@ class CenterHead(nn.Module):
         boxes = torch.empty((B, out_cap, nd), dtype=torch.float32, device=dev)
         scores = torch.empty((B, out_cap), dtype=torch.float32, device=dev)
         labels = torch.empty((B, out_cap), dtype=torch.int32, device=dev)
-        num = torch.zeros(B + 1, dtype=torch.int32, device=dev)   # [B] counts + status word
+        num = torch.empty(B + 1, dtype=torch.int32, device=dev)   # [B] counts + status word (both written)
         rc = L.pn_centerhead_detect(G, len(groups), ctypes.byref(common), nd, out_cap, _lib.ptr(boxes),
                                     _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(num),
                                     ctypes.c_void_p(num.data_ptr() + 4 * B), _lib.ptr(ws), wsb,

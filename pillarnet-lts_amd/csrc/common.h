@@ -66,8 +66,15 @@ struct pnScanGeom {
 };
 pnScanGeom pn_scan_geom(int64_t cells);
 
-// occupancy.hip: bits -> word_rank, (b,y,x) rows, count; optionally zero-fills
-// feature rows [0, count) with `zero_row_bytes` bytes each.
+// occupancy.hip: (bits | byte map | finer level's bits) -> bits, word_rank, (b,y,x) rows, count;
+// optionally zero-fills feature rows [0, count) with `zero_row_bytes` bytes each.
+int pn_occupancy_from_bytes(const unsigned char* bytes, unsigned long long* bits, int64_t cells, int H, int W,
+                            int32_t* word_rank, int32_t* block_sums, int32_t* indices, int32_t* count,
+                            void* zero_rows, int zero_row_bytes, int64_t row_cap, hipStream_t stream);
+int pn_occupancy_downsample(const unsigned long long* fine_bits, int Hi, int Wi, int stride, int pad,
+                            unsigned long long* bits, int batch, int Ho, int Wo, int32_t* word_rank,
+                            int32_t* block_sums, int32_t* indices, int32_t* count, int64_t row_cap,
+                            hipStream_t stream);
 int pn_occupancy_scan(const unsigned long long* bits, int64_t cells, int H, int W,
                       int32_t* word_rank, int32_t* block_sums, int32_t* indices,
                       int32_t* count, void* zero_rows, int zero_row_bytes, int64_t row_cap,

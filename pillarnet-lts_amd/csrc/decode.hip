@@ -22,7 +22,7 @@
 
 static constexpr int DEC_BINS = 8192;
 static constexpr int DEC_LIST = 8192;   // LDS candidate slots per set (sure < pre_max <= 4096, + cut-off bin)
-static constexpr int SEL_THREADS = 1024;
+static constexpr int SEL_THREADS = 256;    // 4 waves: the sort is barrier-bound, small groups sync cheaper
 
 struct DecodeSetDev {
   const float* maps;     // [B, H*W, CH]

@@ -50,34 +50,6 @@ __global__ __launch_bounds__(RULE_THREADS) void subm_rules_kernel(
   }
 }
 
-// mark the output cells of a k3 / stride s / pad p conv that see an active input
-__global__ __launch_bounds__(RULE_THREADS) void down_mark_kernel(
-    const int32_t* __restrict__ indices, const int32_t* __restrict__ count, int cap, int stride,
-    int pad, int Ho, int Wo, unsigned long long* __restrict__ out_bits) {
-  int M = *count;
-  if (M > cap) M = cap;
-  for (int m = blockIdx.x * RULE_THREADS + threadIdx.x; m < M; m += gridDim.x * RULE_THREADS) {
-    const int b = indices[m * 3 + 0], y = indices[m * 3 + 1], x = indices[m * 3 + 2];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int ty = y + pad - ky;
-      if (ty < 0 || ty % stride) continue;
-      const int oy = ty / stride;
-      if (oy >= Ho) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int tx = x + pad - kx;
-        if (tx < 0 || tx % stride) continue;
-        const int ox = tx / stride;
-        if (ox >= Wo) continue;
-        const int cell = (b * Ho + oy) * Wo + ox;
-        const unsigned long long bit = 1ull << (cell & 63);
-        if (!(out_bits[cell >> 6] & bit)) atomicOr(&out_bits[cell >> 6], bit);
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(RULE_THREADS) void down_rules_kernel(
     const int32_t* __restrict__ out_indices, const int32_t* __restrict__ out_count, int out_cap,
     int stride, int pad, int H, int W, const unsigned long long* __restrict__ in_bits,
@@ -138,14 +110,11 @@ extern "C" int pn_spconv_down_rules(const int32_t* in_indices, const int32_t* in
     pn_set_error("pn_spconv_down_rules: scratch too small");
     return PN_ENOSPC;
   }
-  const pnScanGeom sg = pn_scan_geom(cells);
-  PN_CHECK_HIP(hipMemsetAsync(out_bits, 0, (size_t)sg.words * 8, stream));
-  hipLaunchKernelGGL(down_mark_kernel, dim3(rule_blocks(in_cap)), dim3(RULE_THREADS), 0, stream,
-                     in_indices, in_count_dev, in_cap, stride, pad, Ho, Wo,
-                     (unsigned long long*)out_bits);
-  PN_CHECK_LAUNCH("down_mark_kernel");
-  int rc = pn_occupancy_scan((const unsigned long long*)out_bits, cells, Ho, Wo, out_rank,
-                             (int32_t*)scratch, out_indices, out_count_dev, nullptr, 0, out_cap, stream);
+  // output active set straight from the input level's bits (one thread per output cell, ballot =
+  // word): no marking pass over the rows, no atomics
+  int rc = pn_occupancy_downsample((const unsigned long long*)in_bits, H, W, stride, pad,
+                                   (unsigned long long*)out_bits, batch, Ho, Wo, out_rank, (int32_t*)scratch,
+                                   out_indices, out_count_dev, out_cap, stream);
   if (rc != PN_OK) return rc;
   hipLaunchKernelGGL(down_rules_kernel, dim3(rule_blocks(out_cap)), dim3(RULE_THREADS), 0, stream,
                      out_indices, out_count_dev, out_cap, stride, pad, H, W,
@@ -352,9 +321,29 @@ __global__ __launch_bounds__(256) void to_dense_kernel(const T* __restrict__ fea
   }
 }
 
+// channels-last with the level's occupancy index: one thread per (cell, 16-B chunk) writes either
+// the row or zeros -- no memset pass, every output byte is written exactly once
+template <typename T>
+__global__ __launch_bounds__(256) void to_dense_occ_kernel(const T* __restrict__ feats,
+                                                           const unsigned long long* __restrict__ bits,
+                                                           const int32_t* __restrict__ rank, long long cells,
+                                                           int C, int out_ld, T* __restrict__ out) {
+  const int vec = 16 / (int)sizeof(T), cpr = C / vec;
+  const long long total = cells * cpr;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long cell = t / cpr;
+    const int ch = (int)(t - cell * cpr);
+    const int m = pn_occ_rank(bits, rank, (int)cell);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m >= 0) v = *reinterpret_cast<const uint4*>(feats + (size_t)m * C + ch * vec);
+    *reinterpret_cast<uint4*>(out + (size_t)cell * out_ld + ch * vec) = v;
+  }
+}
+
 extern "C" int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* indices,
                                   const int32_t* count_dev, int cap, int batch, int H, int W, int C,
-                                  int channels_last, int out_ld, void* out, pnStream stream_) {
+                                  int channels_last, int out_ld, const uint64_t* occ_bits,
+                                  const int32_t* occ_rank, void* out, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(dtype == PN_DTYPE_F32 || dtype == PN_DTYPE_BF16, "pn_sparse_to_dense: dtype %d", dtype);
   PN_CHECK_ARG(feats && indices && count_dev && out && cap >= 1, "pn_sparse_to_dense: null argument");
@@ -363,12 +352,23 @@ extern "C" int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* i
   if (out_ld <= 0) out_ld = C;
   PN_CHECK_ARG(out_ld >= C && (out_ld * esz) % 16 == 0 && (channels_last || out_ld == C),
                "pn_sparse_to_dense: bad out_ld %d", out_ld);
+  const int blocks = 2048;
+  if (channels_last && occ_bits && occ_rank) {
+    const long long cells = (long long)batch * H * W;
+    if (dtype == PN_DTYPE_BF16)
+      hipLaunchKernelGGL(to_dense_occ_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)feats,
+                         (const unsigned long long*)occ_bits, occ_rank, cells, C, out_ld, (__bf16*)out);
+    else
+      hipLaunchKernelGGL(to_dense_occ_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)feats,
+                         (const unsigned long long*)occ_bits, occ_rank, cells, C, out_ld, (float*)out);
+    PN_CHECK_LAUNCH("to_dense_occ_kernel");
+    return PN_OK;
+  }
   if (out_ld == C) {
     PN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)batch * H * W * C * esz, stream));
   } else {
     PN_CHECK_HIP(hipMemset2DAsync(out, (size_t)out_ld * esz, 0, (size_t)C * esz, (size_t)batch * H * W, stream));
   }
-  const int blocks = 2048;
   if (dtype == PN_DTYPE_BF16)
     hipLaunchKernelGGL(to_dense_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream,
                        (const __bf16*)feats, indices, count_dev, cap, H, W, C, channels_last, out_ld, (__bf16*)out);

@@ -78,7 +78,7 @@ def pillarize(points: List[torch.Tensor], weight, scale, shift, pillar_size, poi
     cap = max(1, min(n, B * g.height * g.width))
     indices = torch.empty((cap, 3), dtype=torch.int32, device=dev)
     feats = torch.empty((cap, C), dtype=torch.float32, device=dev)
-    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    num = torch.empty(1, dtype=torch.int32, device=dev)   # always written by the emit kernel
     ppi = torch.empty(n, dtype=torch.int32, device=dev) if want_point_index else None
     bits_p, rank_p = ctypes.c_void_p(), ctypes.c_void_p()
     rc = L.pn_pillarize(ctypes.byref(g), _lib.ptr(pts), n,

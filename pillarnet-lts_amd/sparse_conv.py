@@ -148,7 +148,7 @@ def _down_rules(x: SparseConvTensor, stride, pad):
     words = (B * Ho * Wo + 63) // 64
     L = _lib.lib()
     out_idx = torch.empty((out_cap, 3), dtype=torch.int32, device=dev)
-    out_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    out_num = torch.empty(1, dtype=torch.int32, device=dev)   # always written by the emit kernel
     out_bits = torch.empty(words, dtype=torch.int64, device=dev)
     out_rank = torch.empty(words, dtype=torch.int32, device=dev)
     nbr = torch.empty((9, out_cap), dtype=torch.int32, device=dev)
@@ -262,7 +262,9 @@ def to_dense(x: SparseConvTensor, channels_last=True, out_channels=None):
         out = torch.empty((B, C, H, W), dtype=feats.dtype, device=feats.device)
     rc = _lib.lib().pn_sparse_to_dense(_dtype_code(feats), _lib.ptr(feats), _lib.ptr(x.indices_cap),
                                        _lib.ptr(x.num_active), x.capacity, B, H, W, C,
-                                       int(channels_last), ld, _lib.ptr(out),
+                                       int(channels_last), ld,
+                                       _lib.ptr(x.occ_bits) if channels_last else None,
+                                       _lib.ptr(x.occ_rank) if channels_last else None, _lib.ptr(out),
                                        _lib.current_stream(feats.device))
     _lib.check(rc, "pn_sparse_to_dense")
     return out[..., :C].permute(0, 3, 1, 2) if channels_last else out

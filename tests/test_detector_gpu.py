@@ -181,3 +181,65 @@ def test_full_size_frame_structure(cuda):
     for t in range(6):
         s = sc[task_of == t]
         assert np.all(np.diff(s) <= 1e-7)
+
+
+# ---- configs[2]: PillarNet-34 + RPNG two-scale neck + per-class NMS + IoU head (Waymo preset) -------
+def small_waymo():
+    cfg = presets.waymo_pillarnet34_fpn()
+    rng = [-12.8, -12.8, -2, 12.8, 12.8, 4.0]
+    cfg.model.reader.pc_range = rng
+    cfg.model.bbox_head.point_cloud_range = rng
+    cfg.test_cfg.post_center_limit_range = [-15, -15, -10.0, 15, 15, 10.0]
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def built_waymo(cuda):
+    torch.manual_seed(1)
+    cfg = small_waymo()
+    model = presets.build(cfg)
+    synth.randomize_bn_(model, seed=2)
+    with torch.no_grad():
+        for th in model.bbox_head.task_heads:
+            th.hm[-1].weight.mul_(8.0)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pts = [synth.waymo_frame(7000, seed=100)[:, :5] * np.array([0.17, 0.17, 1, 1, 1], np.float32)]
+    dets, mid = do.pillarnet_forward(sd, pts, cfg.model, model.test_cfg, return_intermediates=True)
+    return cfg, model, pts, dets, mid
+
+
+def test_waymo_fp32_maps_and_detections(cuda, built_waymo):
+    cfg, model, pts, dets, mid = built_waymo
+    model.to_inference(torch.float32)
+    ex = {"points": [torch.from_numpy(p).to(cuda) for p in pts], "metadata": [None]}
+    with torch.no_grad():
+        bev, feats = model.extract_feat(ex)
+        assert len(bev) == 2
+        for k in range(2):
+            np.testing.assert_allclose(bev[k].cpu().numpy(), mid["bev"][k], rtol=1e-3, atol=1e-3)
+        # decode + per-class NMS on the oracle's maps reproduces the oracle's detections
+        preds = [{k: torch.from_numpy(v).to(cuda) for k, v in d.items()} for d in mid["preds"]]
+        out = model.bbox_head.predict({"metadata": [None]}, preds, model.test_cfg)
+    want = dets[0]
+    if want["min_gap"] < 2e-4:
+        pytest.skip("borderline IoU in the oracle NMS")
+    assert out[0]["box3d_lidar"].shape[1] == 7
+    np.testing.assert_array_equal(out[0]["label_preds"].cpu().numpy(), want["label_preds"])
+    np.testing.assert_allclose(out[0]["scores"].cpu().numpy(), want["scores"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out[0]["box3d_lidar"].cpu().numpy(), want["box3d_lidar"], rtol=1e-5, atol=1e-5)
+    assert want["box3d_lidar"].shape[0] > 10
+
+
+def test_waymo_bf16_hip(cuda, built_waymo):
+    cfg, model, pts, dets, mid = built_waymo
+    model.to_inference(torch.bfloat16)
+    ex = {"points": [torch.from_numpy(p).to(cuda) for p in pts], "metadata": [None]}
+    with torch.no_grad():
+        bev, _ = model.extract_feat(ex)
+        for k in range(2):
+            got = bev[k].float().cpu().numpy()
+            rel = np.linalg.norm(got - mid["bev"][k]) / np.linalg.norm(mid["bev"][k])
+            assert rel <= 4e-2, (k, rel)
+        out = model(ex, return_loss=False)
+    assert out[0]["box3d_lidar"].shape[1] == 7 and out[0]["label_preds"].max() <= 2
+    model.to_inference(torch.float32)
