@@ -91,9 +91,9 @@ def test_decode_and_nms_on_oracle_maps(cuda, built):
     out = model.bbox_head.predict({"metadata": [{}, {}]}, preds, model.test_cfg)
     for b in range(2):
         want = dets[b]
-        if want["min_gap"] < 2e-4:
-            pytest.skip("borderline IoU in the oracle NMS")
         got_boxes = out[b]["box3d_lidar"].cpu().numpy()
+        if got_boxes.shape != want["box3d_lidar"].shape and want["min_gap"] < 2e-4:
+            pytest.skip("borderline IoU in the oracle NMS")
         assert got_boxes.shape == want["box3d_lidar"].shape, (got_boxes.shape, want["box3d_lidar"].shape)
         np.testing.assert_array_equal(out[b]["label_preds"].cpu().numpy(), want["label_preds"])
         np.testing.assert_allclose(out[b]["scores"].cpu().numpy(), want["scores"], rtol=0, atol=2e-6)
@@ -221,7 +221,7 @@ def test_waymo_fp32_maps_and_detections(cuda, built_waymo):
         preds = [{k: torch.from_numpy(v).to(cuda) for k, v in d.items()} for d in mid["preds"]]
         out = model.bbox_head.predict({"metadata": [None]}, preds, model.test_cfg)
     want = dets[0]
-    if want["min_gap"] < 2e-4:
+    if out[0]["box3d_lidar"].shape[0] != want["box3d_lidar"].shape[0] and want["min_gap"] < 2e-4:
         pytest.skip("borderline IoU in the oracle NMS")
     assert out[0]["box3d_lidar"].shape[1] == 7
     np.testing.assert_array_equal(out[0]["label_preds"].cpu().numpy(), want["label_preds"])

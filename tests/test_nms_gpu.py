@@ -17,12 +17,14 @@ IOU_TOL = 2e-5
 
 def _nms_case(cuda, boxes, thr):
     want, gap = iou3d.nms(boxes, thr)
-    if gap < 10 * IOU_TOL:
-        pytest.skip(f"borderline case (gap {gap:g})")
     n = boxes.shape[0]
     keep = torch.LongTensor(max(n, 1))
     m = iou3d_nms.nms_gpu_raw(torch.from_numpy(boxes).to(cuda), keep, thr)
-    np.testing.assert_array_equal(keep[:m].numpy(), want)
+    got = keep[:m].numpy()
+    if not np.array_equal(got, want) and gap < 10 * IOU_TOL:
+        # some consulted pair sits within the IoU tolerance of the threshold: libm last-ulp territory
+        pytest.skip(f"borderline case (gap {gap:g})")
+    np.testing.assert_array_equal(got, want)
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 129, 500, 1000])
@@ -76,9 +78,9 @@ def test_batched_sets_with_device_counts(cuda):
     keep, num = keep.cpu().numpy(), num.cpu().numpy()
     for s in range(S):
         want, gap = iou3d.nms(sets[s][: counts[s]], thr[s])
-        if gap < 10 * IOU_TOL:
-            continue
         want = want[: post[s]]
+        if gap < 10 * IOU_TOL and not (num[s] == len(want) and np.array_equal(keep[s, : num[s]], want)):
+            continue
         assert num[s] == len(want)
         np.testing.assert_array_equal(keep[s, : num[s]], want)
 
