@@ -70,9 +70,11 @@ struct GGArgs {
 // out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
 // missing neighbour (or a weight row past cout) becomes a zero LDS row on the LDS-DMA path
 static constexpr unsigned GG_OOB = 0x80000000u;
+static constexpr int GG_MAX_TAPS = 9;
 
-template <int BM, int BN, int NWM, int NWN, int BK, typename TOut, bool DMA>
+template <int BM, int BN, int NWM, int NWN, int BK, typename TOut, bool DMA, int NBUF>
 __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
+  static_assert(NBUF == 2 || (NBUF == 3 && DMA), "3-deep ring only on the LDS-DMA path");
   constexpr int NT = NWM * NWN * 64;
   constexpr int CH = BK / 8;                 // 16-B chunks per LDS row
   constexpr int WTM = BM / NWM, WTN = BN / NWN;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   constexpr int BUF_BYTES = (BM + BN) * ROWB;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* nbr_lds = reinterpret_cast<int*>(smem + 2 * BUF_BYTES);   // [ntaps][BM] rulebook tile
+  int* nbr_lds = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);   // [ntaps][BM] rulebook tile
 
   {
     const long long g = blockIdx.z;
@@ -219,9 +221,20 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // NBUF == 3: the DMA of stage s+2 is issued while stage s computes and only stage s+1 is waited for
+  // (counted vmcnt, raw barrier: a __syncthreads() would drain everything), so a stage never waits on
+  // loads issued inside itself.
+  constexpr int PIECES_PER_WAVE = ((BM + BN) / ROWS_PER_PIECE) / (NT / 64);
+  static_assert(NBUF == 2 || ((BM + BN) / ROWS_PER_PIECE) % (NT / 64) == 0, "ring needs equal pieces per wave");
   if constexpr (DMA) {
     issue_dma(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NBUF == 3) {
+      if (stages > 1) issue_dma(1, 1);
+      if (stages > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   } else {
     issue(0);
     commit(0);
@@ -229,11 +242,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   __syncthreads();
 
   for (int s = 0; s < stages; ++s) {
-    if (s + 1 < stages) {
-      if constexpr (DMA) issue_dma(s + 1, (s + 1) & 1);
-      else issue(s + 1);
+    if constexpr (DMA) {
+      if (s + NBUF - 1 < stages) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+    } else {
+      if (s + 1 < stages) issue(s + 1);
     }
-    const char* abase = smem + (s & 1) * BUF_BYTES;
+    const char* abase = smem + (s % NBUF) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -255,62 +269,126 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if constexpr (DMA) {
+    if constexpr (DMA && NBUF == 3) {
+      // stage s+1 must have landed; stage s+2 (if issued) may stay in flight
+      if (s + 2 < stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PIECES_PER_WAVE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if constexpr (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     } else {
       if (s + 1 < stages) commit((s + 1) & 1);
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- epilogue: D row = output channel (reg&3) + 8*(reg>>2) + 4*lh, D col = site lr -------------
   TOut* out = reinterpret_cast<TOut*>(a.out);
+  if constexpr (sizeof(TOut) == 2) {
+    // bf16: finish the math per lane (scale/shift, residual, ReLU), park the tile in LDS, then write
+    // whole output rows: 64 lanes x 8 B = 512 contiguous bytes per store instead of 32 rows x 16 B.
+    constexpr int EROW = BN * 2 + 8;                 // +8 B: lanes of a wave walk rows, keep banks apart
+    static_assert((size_t)BM * EROW <= (size_t)NBUF * BUF_BYTES, "epilogue tile must fit the stage buffers");
+    char* et = smem;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * WTM + i * 32 + lr;
-    if (m >= M) continue;
-    const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
+    for (int i = 0; i < TM; ++i) {
+      const int rl = wm * WTM + i * 32 + lr;
+      const int m = m0 + rl;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+      for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;
-        if (c >= a.cout_total) continue;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
-        f32x4 v;
+        for (int g = 0; g < 4; ++g) {
+          const int cl = wn * WTN + j * 32 + 8 * g + 4 * lh;
+          const int c = n0 + cl;
+          f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (c < a.cout_total) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
-        v = v * sc + sh;
-        if (a.residual) {
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + c);
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+            v = v * sc + sh;
+            if (a.residual && m < M) {
+              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + c);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+              for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+            if (a.relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+          *reinterpret_cast<bf16x4*>(et + rl * EROW + cl * 2) = o;
         }
-        if (a.relu) {
+      }
+    }
+    __syncthreads();
+    constexpr int LPR = BN / 4;                      // lanes per output row (4 channels each)
+    constexpr int RPI = 64 / LPR > 0 ? 64 / LPR : 1; // rows per wave-instruction
+    static_assert(LPR <= 64, "row wider than a wavefront");
+    const int sub = lane / LPR, cl = (lane % LPR) * 4;
+    for (int r0 = wave * RPI; r0 < BM; r0 += (NT / 64) * RPI) {
+      const int rl = r0 + sub, m = m0 + rl;
+      if (rl < BM && m < M && n0 + cl < a.cout_total) {
+        const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
+        const uint2 v = *reinterpret_cast<const uint2*>(et + rl * EROW + cl * 2);
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + cl) = v;
+      }
+    }
+  } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WTM + i * 32 + lr;
+      if (m >= M) continue;
+      const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;
+          if (c >= a.cout_total) continue;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+          v = v * sc + sh;
+          if (a.residual) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          OutOps<TOut>::store4(out + orow * a.out_ld + c, v);
         }
-        OutOps<TOut>::store4(out + orow * a.out_ld + c, v);
       }
     }
   }
 }
 
-static constexpr int GG_MAX_TAPS = 9;
-
-template <int BM, int BN, int NWM, int NWN, int BK, typename TOut>
+template <int BM, int BN, int NWM, int NWN, int BK, typename TOut, int NBUF = 2>
 static int launch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = NWM * NWN * 64;
-  constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2 + (size_t)GG_MAX_TAPS * BM * 4;
+  constexpr size_t LDS2 = 2 * (size_t)(BM + BN) * BK * 2 + (size_t)GG_MAX_TAPS * BM * 4;
+  constexpr size_t LDS3 = (size_t)NBUF * (size_t)(BM + BN) * BK * 2 + (size_t)GG_MAX_TAPS * BM * 4;
   static const bool no_dma = getenv("PN_GG_NO_DMA") != nullptr;
+  static const bool no_ring = getenv("PN_GG_NO_RING") != nullptr;
   const bool dma = a.in_bytes != 0 && !no_dma;
-  auto kern = dma ? gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, true>
-                  : gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[dma] && LDS > 32 * 1024) {
+  const bool ring = dma && NBUF == 3 && !no_ring;
+  auto kern = ring ? gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, true, NBUF>
+                   : (dma ? gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, true, 2>
+                          : gather_gemm_kernel<BM, BN, NWM, NWN, BK, TOut, false, 2>);
+  const size_t LDS = ring ? LDS3 : LDS2;
+  static bool attr_set[3] = {false, false, false};
+  const int which = ring ? 2 : (dma ? 1 : 0);
+  if (!attr_set[which] && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_set[dma] = true;
+    attr_set[which] = true;
   }
   const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN), groups);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, stream, a);
@@ -329,7 +407,7 @@ static int dispatch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   if (N <= 32) return launch_gg<128, 32, 4, 1, 64, TOut>(a, groups, stream);
   if (N <= 64) return launch_gg<128, 64, 2, 2, 64, TOut>(a, groups, stream);
   if (force && N > 128) {
-    if (force[0] == 'A') return launch_gg<128, 256, 2, 4, 64, TOut>(a, groups, stream);
+    if (force[0] == 'A') return launch_gg<128, 256, 2, 4, 64, TOut, 3>(a, groups, stream);
     if (force[0] == 'B') return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
     if (force[0] == 'E') return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
     if (force[0] == 'F') return launch_gg<64, 256, 1, 4, 64, TOut>(a, groups, stream);
@@ -339,7 +417,7 @@ static int dispatch_gg(const GGArgs& a, int groups, hipStream_t stream) {
     return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
   }
   // wide outputs: one 128 x 256 tile per workgroup when that still fills the chip, else split
-  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut>(a, groups, stream);
+  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut, 3>(a, groups, stream);
   if (rows >= 64 * 96 * 2) return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
   return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
 }
