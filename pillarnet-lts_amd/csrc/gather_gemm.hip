@@ -407,17 +407,19 @@ static int dispatch_gg(const GGArgs& a, int groups, hipStream_t stream) {
   if (N <= 32) return launch_gg<128, 32, 4, 1, 64, TOut>(a, groups, stream);
   if (N <= 64) return launch_gg<128, 64, 2, 2, 64, TOut>(a, groups, stream);
   if (force && N > 128) {
-    if (force[0] == 'A') return launch_gg<128, 256, 2, 4, 64, TOut, 3>(a, groups, stream);
+    if (force[0] == 'A') return launch_gg<128, 256, 2, 4, 64, TOut>(a, groups, stream);
     if (force[0] == 'B') return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
     if (force[0] == 'E') return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
     if (force[0] == 'F') return launch_gg<64, 256, 1, 4, 64, TOut>(a, groups, stream);
+    if (force[0] == 'G') return launch_gg<256, 256, 4, 4, 64, TOut>(a, groups, stream);
+    if (force[0] == 'R') return launch_gg<128, 256, 2, 4, 64, TOut, 3>(a, groups, stream);
   }
   if (N <= 128) {
     if (rows * (long long)groups >= 128 * 192) return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
     return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
   }
   // wide outputs: one 128 x 256 tile per workgroup when that still fills the chip, else split
-  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut, 3>(a, groups, stream);
+  if (rows >= 128 * 192) return launch_gg<128, 256, 2, 4, 64, TOut>(a, groups, stream);
   if (rows >= 64 * 96 * 2) return launch_gg<128, 128, 2, 2, 64, TOut>(a, groups, stream);
   return launch_gg<64, 128, 2, 2, 64, TOut>(a, groups, stream);
 }
