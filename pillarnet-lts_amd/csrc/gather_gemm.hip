@@ -284,11 +284,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
 
   // ---- epilogue: D row = output channel (reg&3) + 8*(reg>>2) + 4*lh, D col = site lr -------------
   TOut* out = reinterpret_cast<TOut*>(a.out);
-  if constexpr (sizeof(TOut) == 2) {
+  constexpr bool LDS_EPILOGUE = sizeof(TOut) == 2 && (size_t)BM * (BN * 2 + 8) <= (size_t)NBUF * BUF_BYTES;
+  if constexpr (LDS_EPILOGUE) {
     // bf16: finish the math per lane (scale/shift, residual, ReLU), park the tile in LDS, then write
     // whole output rows: 64 lanes x 8 B = 512 contiguous bytes per store instead of 32 rows x 16 B.
     constexpr int EROW = BN * 2 + 8;                 // +8 B: lanes of a wave walk rows, keep banks apart
-    static_assert((size_t)BM * EROW <= (size_t)NBUF * BUF_BYTES, "epilogue tile must fit the stage buffers");
     char* et = smem;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
