@@ -65,6 +65,7 @@ struct GGArgs {
   const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
   // grouped launch (blockIdx.z = group g): element offsets added per group
   long long g_in, g_wt, g_ss, g_out;
+  int rotate_taps;
 };
 
 // out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
     bx = x * q + (x < r ? x : r) + (bx >> 3);
   }
   const int m0 = bx * BM;
+  const int tap_rot = a.rotate_taps ? bx % a.ntaps : 0;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as a scalar: keeps the LDS-DMA descriptor choice, M0 base and branches wave-uniform
@@ -117,6 +119,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
   const int kchunks = a.cin / BK;            // stages per tap
+  // tiles start at different taps: otherwise every CU of the chip asks L2 for the same 32 KB weight
+  // slice at the same moment (the sum order per tile changes, results stay run-to-run identical)
+  static_assert(true, "");
   const int stages = a.ntaps * kchunks;
 
   // ---- this thread's share of a stage: which (row, chunk) pieces it moves -----------------------
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   }
   (void)PIECES;
   auto issue_dma = [&](int s, int buf) {
-    const int tap = s / kchunks, kc = s - tap * kchunks;
+    const int tap0 = s / kchunks, kc = s - tap0 * kchunks;
+    const int tap = (tap0 + tap_rot) % a.ntaps;
     char* base = smem + buf * BUF_BYTES;
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   };
 
   auto issue = [&](int s) {
-    const int tap = s / kchunks, kc = s - tap * kchunks;
+    const int tap0 = s / kchunks, kc = s - tap0 * kchunks;
+    const int tap = (tap0 + tap_rot) % a.ntaps;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -467,6 +474,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
   a.g_in = a.g_wt = a.g_ss = a.g_out = 0;
+  a.rotate_taps = getenv("PN_GG_ROTATE") != nullptr;
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   return out_fp32 ? dispatch_gg<float>(a, 1, stream) : dispatch_gg<__bf16>(a, 1, stream);
 }
@@ -493,6 +501,7 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
   a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;
   a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
+  a.rotate_taps = 0;
   return out_fp32 ? dispatch_gg<float>(a, groups, stream) : dispatch_gg<__bf16>(a, groups, stream);
 }
 
