@@ -154,38 +154,38 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   constexpr int PIECES = (BM + BN) / 8;            // per stage (rows are BK*2 = 8*16 B or 4*16 B)
   constexpr int ROWS_PER_PIECE = 1024 / ROWB;      // 8 (BK 64) or 16 (BK 32)
   constexpr int NPIECE = ((BM + BN) / ROWS_PER_PIECE + NT / 64 - 1) / (NT / 64);
-  __amdgpu_buffer_rsrc_t rs_in, rs_wt;
-  if constexpr (DMA) {
-    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, (int)((size_t)a.ntaps * a.cout_total * a.cin * 2), 0x00020000);
-  }
+  __amdgpu_buffer_rsrc_t rs_in;
+  if constexpr (DMA) rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
   (void)PIECES;
-  auto issue_dma = [&](int s, int buf) {
+  auto issue_piece = [&](int s, int buf, int j) {
     const int tap0 = s / kchunks, kc = s - tap0 * kchunks;
     const int tap = (tap0 + tap_rot) % a.ntaps;
     char* base = smem + buf * BUF_BYTES;
-#pragma unroll
-    for (int j = 0; j < NPIECE; ++j) {
-      const int piece = wave + j * (NT / 64);       // wave-uniform
-      if (piece * ROWS_PER_PIECE >= BM + BN) break;
-      const int row = piece * ROWS_PER_PIECE + lane / CH;   // row inside [acts | weights]
-      const int slot = lane % CH;
-      auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
-      if (piece * ROWS_PER_PIECE < BM) {   // wave-uniform: a piece never straddles the two tiles
-        const int src = nbr_lds[tap * BM + row];
-        const unsigned off = src >= 0 ? (unsigned)src * (unsigned)(a.in_ld * 2) + (unsigned)(kc * ROWB) +
-                                            (unsigned)((slot ^ swz<BK>(row)) << 4)
-                                      : GG_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, 0, 0, 0);
-      } else {
-        const int r = row - BM, n = n0 + r;
-        const unsigned off = n < a.cout_total
-                                 ? ((unsigned)(tap * a.cout_total + n) * (unsigned)a.cin) * 2u + (unsigned)(kc * ROWB) +
-                                       (unsigned)((slot ^ swz<BK>(r)) << 4)
-                                 : GG_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, lds, 16, off, 0, 0, 0);
-      }
+    const int piece = wave + j * (NT / 64);       // wave-uniform
+    if (piece * ROWS_PER_PIECE >= BM + BN) return;
+    const int row = piece * ROWS_PER_PIECE + lane / CH;   // row inside [acts | weights]
+    const int slot = lane % CH;
+    auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+    if (piece * ROWS_PER_PIECE < BM) {   // wave-uniform: a piece never straddles the two tiles
+      const int src = nbr_lds[tap * BM + row];
+      const unsigned off = src >= 0 ? (unsigned)src * (unsigned)(a.in_ld * 2) + (unsigned)(kc * ROWB) +
+                                          (unsigned)((slot ^ swz<BK>(row)) << 4)
+                                    : GG_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, 0, 0, 0);
+    } else {
+      // weights: plain flat addresses (one descriptor in the kernel keeps hipcc from merging the two
+      // loads behind a select of descriptors + waterfall loop).  Rows past cout are clamped: their
+      // products land in accumulator rows the epilogue never stores.
+      const int r = row - BM;
+      int n = n0 + r;
+      if (n >= a.cout_total) n = a.cout_total - 1;
+      const __bf16* src = a.wt + ((size_t)(tap * a.cout_total + n) * a.cin + kc * BK + ((slot ^ swz<BK>(r)) << 3));
+      __builtin_amdgcn_global_load_lds(src, lds, 16, 0, 0);
     }
+  };
+  auto issue_dma = [&](int s, int buf) {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) issue_piece(s, buf, j);
   };
 
   auto issue = [&](int s) {
@@ -249,8 +249,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   __syncthreads();
 
   for (int s = 0; s < stages; ++s) {
+    constexpr int KSTEPS = BK / 16;
+    constexpr int PPK = (NPIECE + KSTEPS - 2) / (KSTEPS - 1 > 0 ? KSTEPS - 1 : 1);   // DMA pieces per k-step
+    constexpr bool SPREAD = DMA && NBUF == 2 && KSTEPS > 1;
+    const bool more = s + NBUF - 1 < stages;
     if constexpr (DMA) {
-      if (s + NBUF - 1 < stages) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+      if constexpr (!SPREAD) {
+        if (more) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+      }
     } else {
       if (s + 1 < stages) issue(s + 1);
     }
@@ -281,6 +287,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);
+      // the next stage's LDS-DMA pieces go out behind this k-step's MFMAs (an MFMA holds the vector
+      // issue port for 8 of its 32 cycles, the DMA address work overlaps the rest) instead of in one
+      // burst at the top of the stage while the matrix pipe idles
+      if constexpr (SPREAD) {
+        if (more && ks + 1 < KSTEPS) {
+#pragma unroll
+          for (int q = 0; q < PPK; ++q)
+            if (ks * PPK + q < NPIECE) issue_piece(s + 1, (s + 1) & 1, ks * PPK + q);
+        }
+      }
     }
     // pin the issue order hipcc would otherwise undo (it re-serialises reads behind the MFMAs that
     // consume the previous fragments): reads(0) | reads(k+1), MFMAs(k) ...
@@ -289,6 +305,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
     for (int ks = 0; ks < BK / 16; ++ks) {
       if (ks + 1 < BK / 16) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      if constexpr (SPREAD) {
+        if (ks + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x020, PPK, 0);
+      }
     }
     if constexpr (DMA && NBUF == 3) {
       // stage s+1 must have landed; stage s+2 (if issued) may stay in flight
