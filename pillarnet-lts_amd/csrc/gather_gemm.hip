@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   for (int s = 0; s < stages; ++s) {
     constexpr int KSTEPS = BK / 16;
     constexpr int PPK = (NPIECE + KSTEPS - 2) / (KSTEPS - 1 > 0 ? KSTEPS - 1 : 1);   // DMA pieces per k-step
-    constexpr bool SPREAD = DMA && NBUF == 2 && KSTEPS > 1;
+    constexpr bool SPREAD = false && DMA && NBUF == 2 && KSTEPS > 1;   // measured slower than a burst at the stage top
     const bool more = s + NBUF - 1 < stages;
     if constexpr (DMA) {
       if constexpr (!SPREAD) {
