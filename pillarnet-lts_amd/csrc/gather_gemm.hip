@@ -65,7 +65,6 @@ struct GGArgs {
   const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
   // grouped launch (blockIdx.z = group g): element offsets added per group
   long long g_in, g_wt, g_ss, g_out;
-  int rotate_taps;
 };
 
 // out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
@@ -110,7 +109,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
     bx = x * q + (x < r ? x : r) + (bx >> 3);
   }
   const int m0 = bx * BM;
-  const int tap_rot = a.rotate_taps ? bx % a.ntaps : 0;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as a scalar: keeps the LDS-DMA descriptor choice, M0 base and branches wave-uniform
@@ -119,9 +117,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
   const int kchunks = a.cin / BK;            // stages per tap
-  // tiles start at different taps: otherwise every CU of the chip asks L2 for the same 32 KB weight
-  // slice at the same moment (the sum order per tile changes, results stay run-to-run identical)
-  static_assert(true, "");
   const int stages = a.ntaps * kchunks;
 
   // ---- this thread's share of a stage: which (row, chunk) pieces it moves -----------------------
@@ -154,43 +149,41 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   constexpr int PIECES = (BM + BN) / 8;            // per stage (rows are BK*2 = 8*16 B or 4*16 B)
   constexpr int ROWS_PER_PIECE = 1024 / ROWB;      // 8 (BK 64) or 16 (BK 32)
   constexpr int NPIECE = ((BM + BN) / ROWS_PER_PIECE + NT / 64 - 1) / (NT / 64);
-  __amdgpu_buffer_rsrc_t rs_in;
-  if constexpr (DMA) rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_in, rs_wt;
+  if constexpr (DMA) {
+    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, (int)((size_t)a.ntaps * a.cout_total * a.cin * 2), 0x00020000);
+  }
   (void)PIECES;
-  auto issue_piece = [&](int s, int buf, int j) {
-    const int tap0 = s / kchunks, kc = s - tap0 * kchunks;
-    const int tap = (tap0 + tap_rot) % a.ntaps;
-    char* base = smem + buf * BUF_BYTES;
-    const int piece = wave + j * (NT / 64);       // wave-uniform
-    if (piece * ROWS_PER_PIECE >= BM + BN) return;
-    const int row = piece * ROWS_PER_PIECE + lane / CH;   // row inside [acts | weights]
-    const int slot = lane % CH;
-    auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
-    if (piece * ROWS_PER_PIECE < BM) {   // wave-uniform: a piece never straddles the two tiles
-      const int src = nbr_lds[tap * BM + row];
-      const unsigned off = src >= 0 ? (unsigned)src * (unsigned)(a.in_ld * 2) + (unsigned)(kc * ROWB) +
-                                          (unsigned)((slot ^ swz<BK>(row)) << 4)
-                                    : GG_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, 0, 0, 0);
-    } else {
-      // weights: plain flat addresses (one descriptor in the kernel keeps hipcc from merging the two
-      // loads behind a select of descriptors + waterfall loop).  Rows past cout are clamped: their
-      // products land in accumulator rows the epilogue never stores.
-      const int r = row - BM;
-      int n = n0 + r;
-      if (n >= a.cout_total) n = a.cout_total - 1;
-      const __bf16* src = a.wt + ((size_t)(tap * a.cout_total + n) * a.cin + kc * BK + ((slot ^ swz<BK>(r)) << 3));
-      __builtin_amdgcn_global_load_lds(src, lds, 16, 0, 0);
-    }
-  };
   auto issue_dma = [&](int s, int buf) {
+    const int tap = s / kchunks, kc = s - tap * kchunks;
+    char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-    for (int j = 0; j < NPIECE; ++j) issue_piece(s, buf, j);
+    for (int j = 0; j < NPIECE; ++j) {
+      const int piece = wave + j * (NT / 64);       // wave-uniform
+      if (piece * ROWS_PER_PIECE >= BM + BN) break;
+      const int row = piece * ROWS_PER_PIECE + lane / CH;   // row inside [acts | weights]
+      const int slot = lane % CH;
+      auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+      if (piece * ROWS_PER_PIECE < BM) {   // wave-uniform: a piece never straddles the two tiles
+        const int src = nbr_lds[tap * BM + row];
+        const unsigned off = src >= 0 ? (unsigned)src * (unsigned)(a.in_ld * 2) + (unsigned)(kc * ROWB) +
+                                            (unsigned)((slot ^ swz<BK>(row)) << 4)
+                                      : GG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, 0, 0, 0);
+      } else {
+        const int r = row - BM, n = n0 + r;
+        const unsigned off = n < a.cout_total
+                                 ? ((unsigned)(tap * a.cout_total + n) * (unsigned)a.cin) * 2u + (unsigned)(kc * ROWB) +
+                                       (unsigned)((slot ^ swz<BK>(r)) << 4)
+                                 : GG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, lds, 16, off, 0, 0, 0);
+      }
+    }
   };
 
   auto issue = [&](int s) {
-    const int tap0 = s / kchunks, kc = s - tap0 * kchunks;
-    const int tap = (tap0 + tap_rot) % a.ntaps;
+    const int tap = s / kchunks, kc = s - tap * kchunks;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -249,65 +242,32 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   __syncthreads();
 
   for (int s = 0; s < stages; ++s) {
-    constexpr int KSTEPS = BK / 16;
-    constexpr int PPK = (NPIECE + KSTEPS - 2) / (KSTEPS - 1 > 0 ? KSTEPS - 1 : 1);   // DMA pieces per k-step
-    constexpr bool SPREAD = false && DMA && NBUF == 2 && KSTEPS > 1;   // measured slower than a burst at the stage top
-    const bool more = s + NBUF - 1 < stages;
     if constexpr (DMA) {
-      if constexpr (!SPREAD) {
-        if (more) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
-      }
+      if (s + NBUF - 1 < stages) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
     } else {
       if (s + 1 < stages) issue(s + 1);
     }
     const char* abase = smem + (s % NBUF) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
-    // fragments of k-step ks+1 are requested from LDS before the MFMAs of k-step ks issue, so the
-    // LDS latency (which was 43 % of the wave cycles in SQ_WAIT_ANY) hides under 4 MFMAs
-    bf16x8 fa[2][TM], fw[2][TN];
-    auto load_frags = [&](int ks, int slot) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fw[TN];
       const int chunk = 2 * ks + lh;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WTM + i * 32 + lr;
-        fa[slot][i] = *reinterpret_cast<const bf16x8*>(abase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
+        fa[i] = *reinterpret_cast<const bf16x8*>(abase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 32 + lr;
-        fw[slot][j] = *reinterpret_cast<const bf16x8*>(wbase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
+        fw[j] = *reinterpret_cast<const bf16x8*>(wbase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
       }
-    };
-    load_frags(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);
-      // the next stage's LDS-DMA pieces go out behind this k-step's MFMAs (an MFMA holds the vector
-      // issue port for 8 of its 32 cycles, the DMA address work overlaps the rest) instead of in one
-      // burst at the top of the stage while the matrix pipe idles
-      if constexpr (SPREAD) {
-        if (more && ks + 1 < KSTEPS) {
-#pragma unroll
-          for (int q = 0; q < PPK; ++q)
-            if (ks * PPK + q < NPIECE) issue_piece(s + 1, (s + 1) & 1, ks * PPK + q);
-        }
-      }
-    }
-    // pin the issue order hipcc would otherwise undo (it re-serialises reads behind the MFMAs that
-    // consume the previous fragments): reads(0) | reads(k+1), MFMAs(k) ...
-    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-      if constexpr (SPREAD) {
-        if (ks + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x020, PPK, 0);
-      }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     }
     if constexpr (DMA && NBUF == 3) {
       // stage s+1 must have landed; stage s+2 (if issued) may stay in flight
@@ -493,7 +453,6 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
   a.g_in = a.g_wt = a.g_ss = a.g_out = 0;
-  a.rotate_taps = getenv("PN_GG_ROTATE") != nullptr;
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   return out_fp32 ? dispatch_gg<float>(a, 1, stream) : dispatch_gg<__bf16>(a, 1, stream);
 }
@@ -520,7 +479,6 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
   a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;
   a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
-  a.rotate_taps = 0;
   return out_fp32 ? dispatch_gg<float>(a, groups, stream) : dispatch_gg<__bf16>(a, groups, stream);
 }
 
