@@ -70,9 +70,6 @@ struct GGArgs {
 // out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
 // missing neighbour (or a weight row past cout) becomes a zero LDS row on the LDS-DMA path
 static constexpr unsigned GG_OOB = 0x80000000u;
-// weight tiles are streamed once per workgroup: non-temporal, so they do not evict the activation
-// lines that the next taps (same rows shifted by one site) re-read from the CU's L1
-static constexpr int GG_WT_AUX = 2;
 static constexpr int GG_MAX_TAPS = 9;
 
 template <int BM, int BN, int NWM, int NWN, int BK, typename TOut, bool DMA, int NBUF>
@@ -159,7 +156,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   }
   (void)PIECES;
   auto issue_dma = [&](int s, int buf) {
-    const int kc = s / a.ntaps, tap = s - kc * a.ntaps;   // channel-chunk major, taps inner (see header)
+    const int tap = s / kchunks, kc = s - tap * kchunks;
     char* base = smem + buf * BUF_BYTES;
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
@@ -180,13 +177,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
                                  ? ((unsigned)(tap * a.cout_total + n) * (unsigned)a.cin) * 2u + (unsigned)(kc * ROWB) +
                                        (unsigned)((slot ^ swz<BK>(r)) << 4)
                                  : GG_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, lds, 16, off, 0, 0, GG_WT_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, lds, 16, off, 0, 0, 0);
       }
     }
   };
 
   auto issue = [&](int s) {
-    const int kc = s / a.ntaps, tap = s - kc * a.ntaps;   // channel-chunk major, taps inner (see header)
+    const int tap = s / kchunks, kc = s - tap * kchunks;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       uint4 v = make_uint4(0, 0, 0, 0);
