@@ -65,6 +65,7 @@ struct GGArgs {
   const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
   // grouped launch (blockIdx.z = group g): element offsets added per group
   long long g_in, g_wt, g_ss, g_out;
+  int diag;                // 1: skip LDS reads + MFMAs (staging-rate probe), 2: skip staging (math-rate probe)
 };
 
 // out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
@@ -243,12 +244,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
 
   for (int s = 0; s < stages; ++s) {
     if constexpr (DMA) {
-      if (s + NBUF - 1 < stages) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+      if (s + NBUF - 1 < stages && a.diag != 2) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
     } else {
       if (s + 1 < stages) issue(s + 1);
     }
     const char* abase = smem + (s % NBUF) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
+    if (a.diag != 1)
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fa[TM], fw[TN];
@@ -453,6 +455,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
   a.g_in = a.g_wt = a.g_ss = a.g_out = 0;
+  { const char* d = getenv("PN_GG_DIAG"); a.diag = d ? atoi(d) : 0; }
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   return out_fp32 ? dispatch_gg<float>(a, 1, stream) : dispatch_gg<__bf16>(a, 1, stream);
 }
@@ -479,6 +482,7 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
   a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;
   a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
+  a.diag = 0;
   return out_fp32 ? dispatch_gg<float>(a, groups, stream) : dispatch_gg<__bf16>(a, groups, stream);
 }
 
