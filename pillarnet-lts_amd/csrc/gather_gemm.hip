@@ -250,38 +250,26 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
     }
     const char* abase = smem + (s % NBUF) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
-    if (a.diag != 1) {
-      // fragments of k-step ks+1 are requested from LDS before the MFMAs of k-step ks issue
-      bf16x8 fa[2][TM], fw[2][TN];
-      auto load_frags = [&](int ks, int slot) {
-        const int chunk = 2 * ks + lh;
+    if (a.diag != 1)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * WTM + i * 32 + lr;
-          fa[slot][i] = *reinterpret_cast<const bf16x8*>(abase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
-        }
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fw[TN];
+      const int chunk = 2 * ks + lh;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * WTN + j * 32 + lr;
-          fw[slot][j] = *reinterpret_cast<const bf16x8*>(wbase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
-        }
-      };
-      load_frags(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        fa[i] = *reinterpret_cast<const bf16x8*>(abase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        if (ks + 1 < BK / 16) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + lr;
+        fw[j] = *reinterpret_cast<const bf16x8*>(wbase + row * ROWB + ((chunk ^ swz<BK>(row)) << 4));
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     }
     if constexpr (DMA && NBUF == 3) {
       // stage s+1 must have landed; stage s+2 (if issued) may stay in flight
