@@ -22,7 +22,7 @@
 
 static constexpr int DEC_BINS = 8192;
 static constexpr int DEC_LIST = 8192;   // LDS candidate slots per set (sure < pre_max <= 4096, + cut-off bin)
-static constexpr int SEL_THREADS = 256;    // 4 waves: the sort is barrier-bound, small groups sync cheaper
+static constexpr int SEL_THREADS = 1024;
 
 struct DecodeSetDev {
   const float* maps;     // [B, H*W, CH]
@@ -180,15 +180,27 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
 
   // ---- collect ----------------------------------------------------------------------------------
   const unsigned* kk = keys + S.key_offset + (long long)b * cells;
-  for (int cell = tid; cell < cells; cell += SEL_THREADS) {
-    const unsigned key = kk[cell];
-    if (!key) continue;
-    int bin = key > C.key_lo ? (int)((key - C.key_lo) >> C.key_shift) : 0;
-    if (bin >= DEC_BINS) bin = DEC_BINS - 1;
-    if (bin >= cut) {
-      const int pos = atomicAdd(&s_cnt, 1);
-      if (pos < DEC_LIST)
-        list[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cell);
+  // keys are fetched 8 at a time per thread (independent loads in flight) -- a load-test-append loop
+  // serialises one L2 round trip per cell and was most of this kernel's time
+  for (int base = 0; base < cells; base += SEL_THREADS * 8) {
+    unsigned kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int cell = base + u * SEL_THREADS + tid;
+      kv[u] = cell < cells ? kk[cell] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned key = kv[u];
+      if (!key) continue;
+      const int cell = base + u * SEL_THREADS + tid;
+      int bin = key > C.key_lo ? (int)((key - C.key_lo) >> C.key_shift) : 0;
+      if (bin >= DEC_BINS) bin = DEC_BINS - 1;
+      if (bin >= cut) {
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < DEC_LIST)
+          list[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cell);
+      }
     }
   }
   __syncthreads();

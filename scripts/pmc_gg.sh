@@ -8,14 +8,14 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 scripts/gg_one.py $1 $2 $3 6 > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 scripts/gg_one.py "$@" > $OUT/p$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob("gpurun_out/pmc_gg/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gather_gemm" not in r["Kernel_Name"]:
+        if "gather_gemm" not in r["Kernel_Name"] or "Li128ELi256E" not in r["Kernel_Name"] and "128, 256" not in r["Kernel_Name"]:
             continue
         a = agg[r["Counter_Name"]]
         a[0] += 1
