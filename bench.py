@@ -119,8 +119,15 @@ def main():
         flops = 2.0 * cin * cout * pairs
         peak = 2500.0 if dtype == torch.bfloat16 else 157.3
         ach = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"spconv_igemm_kernel<{args.dtype},{cin},{cout}>", "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same shape)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f).get(f"spconv_{cin}x{cout}", {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
+        roof = {"bound": "mfma", "kernel": f"gather_gemm_kernel<128,256,2,4,64,{args.dtype}> (sparse SubM {cin}->{cout})",
+                "achieved": round(ach, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "active_pairs": pairs, "rows": rows}
     sparse_conv.EVENT_PROBE.update(shape=None, events=[], rules=None, rows=None)
 
