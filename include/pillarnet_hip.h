@@ -259,6 +259,40 @@ int pn_tap_sum(const float* z, int z_ld, long long z_group_stride, const int32_t
                int nbr_stride, int rows, int channels, int groups, const float* bias,
                float* out, int out_ld, long long out_group_stride, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * Unfused / training-path operators with the reference's pybind contracts
+ * (det3d/ops/pillar_ops/src/pillar_api.cpp:10-21; all tensors caller-allocated, on the device).
+ * ------------------------------------------------------------------------ */
+
+/* pillar_cuda.create_point_pillar_index_stack_wrapper (pillar_ops.cpp:15-36): pts_xy i32[N,2],
+ * pts_batch_cnt i32[B] (device), pillars_mask u8/bool[B,H,W] pre-zeroed, point_pillar_index
+ * i32[N] pre-filled with -1. */
+int pn_create_point_pillar_index_stack(const int32_t* pts_xy, const int32_t* pts_batch_cnt, int N,
+                                       int B, int H, int W, uint8_t* pillars_mask,
+                                       int32_t* point_pillar_index, pnStream stream);
+/* pillar_cuda.create_pillar_indices_wrapper (pillar_ops.cpp:39-55): pillars_position i32[B,H,W]
+ * (-1 = empty) -> pillar_indices i32[M,3]. */
+int pn_create_pillar_indices(const int32_t* pillars_position, int B, int H, int W,
+                             int32_t* pillar_indices, pnStream stream);
+/* pillar_cuda.gather_indice_wrapper / gather_feature_wrapper (group_ops.cpp:4-38). */
+int pn_gather_indice(const int32_t* index, int L, const int32_t* indices, int32_t* outs, pnStream stream);
+int pn_gather_feature(const int32_t* index, int L, const float* features, int C, float* outs,
+                      pnStream stream);
+/* pillar_cuda.scatter_max_wrapper (scatter_ops.cpp:7-24): out[m,c] = max(0, max_{p: index[p]=m}
+ * src[p,c]); arg[m,c] = lowest such p (or -1 where out stayed 0); arg may be NULL.  One pass,
+ * deterministic.  workspace: pn_scatter_max_workspace_bytes(M, C). */
+size_t pn_scatter_max_workspace_bytes(int M, int C);
+int pn_scatter_max(const int32_t* index, const float* src, int L, int C, int M, int32_t* arg,
+                   float* out, void* workspace, size_t workspace_bytes, pnStream stream);
+/* pillar_cuda.scatter_max_grad_wrapper (scatter_ops.cpp:26-41): grad_src (pre-zeroed [L,C])
+ * receives grad_out[m,c] at row arg[m,c]. */
+int pn_scatter_max_grad(const float* grad_out, const int32_t* arg, int M, int C, float* grad_src,
+                        pnStream stream);
+/* Inverse rulebook for the sparse-conv data gradient: inv[k*inv_stride + j] = the output row m
+ * with nbr[k*nbr_stride + m] == j, or -1 (inv is fully initialised here). */
+int pn_spconv_invert_rules(const int32_t* nbr, int nbr_stride, const int32_t* out_count_dev,
+                           int out_cap, int32_t* inv, int inv_stride, pnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

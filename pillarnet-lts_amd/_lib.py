@@ -87,6 +87,16 @@ SIGNATURES = {
                                        c_void_p]),
     "pn_tap_sum": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                            c_void_p, c_int, ctypes.c_longlong, c_void_p]),
+    "pn_create_point_pillar_index_stack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                                   c_void_p, c_void_p]),
+    "pn_create_pillar_indices": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_gather_indice": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "pn_gather_feature": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "pn_scatter_max_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pn_scatter_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
+    "pn_scatter_max_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pn_spconv_invert_rules": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -286,6 +286,9 @@ extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, long long i
   PN_CONV_CASE(128, 128, 4)
   PN_CONV_CASE(128, 256, 2)
   PN_CONV_CASE(256, 256, 2)
+  PN_CONV_CASE(64, 32, 4)    // data gradients of the strided convs
+  PN_CONV_CASE(128, 64, 4)
+  PN_CONV_CASE(256, 128, 4)
   pn_set_error("pn_spconv_forward: no kernel built for %d -> %d channels", cin, cout);
   return PN_EINVAL;
 }

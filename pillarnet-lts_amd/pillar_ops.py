@@ -164,8 +164,147 @@ class PillarMaxPooling(nn.Module):
         if len(self.shared_mlps) != 3 or self.activation != 'relu':
             raise NotImplementedError("the fused HIP reader implements one Linear+BN1d+ReLU layer")
         if self.training:
-            raise NotImplementedError("training-mode BatchNorm in the fused reader is not built yet")
+            raise NotImplementedError("the fused reader is inference-only; training goes through forward_unfused")
         w, scale, shift = self._fold()
         sp, ppi = pillarize(points, w, scale, shift, self.groups.pillar_size,
                             self.groups.point_cloud_range, want_point_index)
         return (sp, ppi) if want_point_index else sp
+
+
+# =================================================================================================
+# Unfused / training path: the reference's operator surface (det3d/ops/pillar_ops/{group_utils,
+# scatter_utils,pillar_utils}.py) on the HIP C ABI, differentiable where the reference's is.
+# =================================================================================================
+class pillar_cuda:
+    """Drop-in for the reference's `pillar_cuda` pybind module (pillar_api.cpp:10-21): same function
+    names, argument order and out-parameter style; every call returns 1."""
+
+    @staticmethod
+    def create_point_pillar_index_stack_wrapper(pts_xy, pts_batch_cnt, pillars_mask, point_pillar_index):
+        B, H, W = pillars_mask.shape
+        rc = _lib.lib().pn_create_point_pillar_index_stack(
+            _lib.ptr(pts_xy), _lib.ptr(pts_batch_cnt), pts_xy.shape[0], B, H, W, _lib.ptr(pillars_mask),
+            _lib.ptr(point_pillar_index), _lib.current_stream(pts_xy.device))
+        _lib.check(rc, "pn_create_point_pillar_index_stack")
+        return 1
+
+    @staticmethod
+    def create_pillar_indices_wrapper(pillars_position, pillar_indices):
+        B, H, W = pillars_position.shape
+        rc = _lib.lib().pn_create_pillar_indices(_lib.ptr(pillars_position), B, H, W, _lib.ptr(pillar_indices),
+                                                 _lib.current_stream(pillars_position.device))
+        _lib.check(rc, "pn_create_pillar_indices")
+        return 1
+
+    @staticmethod
+    def gather_indice_wrapper(index, indices, outs):
+        rc = _lib.lib().pn_gather_indice(_lib.ptr(index), index.shape[0], _lib.ptr(indices), _lib.ptr(outs),
+                                         _lib.current_stream(index.device))
+        _lib.check(rc, "pn_gather_indice")
+        return 1
+
+    @staticmethod
+    def gather_feature_wrapper(index, features, outs):
+        rc = _lib.lib().pn_gather_feature(_lib.ptr(index), index.shape[0], _lib.ptr(features), features.shape[1],
+                                          _lib.ptr(outs), _lib.current_stream(index.device))
+        _lib.check(rc, "pn_gather_feature")
+        return 1
+
+    @staticmethod
+    def scatter_max_wrapper(index, src, arg, out):
+        L, C = src.shape
+        M = out.shape[0]
+        Lb = _lib.lib()
+        wsb = Lb.pn_scatter_max_workspace_bytes(max(M, 1), C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=src.device)
+        rc = Lb.pn_scatter_max(_lib.ptr(index), _lib.ptr(src), L, C, M, _lib.ptr(arg), _lib.ptr(out), _lib.ptr(ws),
+                               wsb, _lib.current_stream(src.device))
+        _lib.check(rc, "pn_scatter_max")
+        return 1
+
+    @staticmethod
+    def scatter_max_grad_wrapper(grad_out, arg, grad_src):
+        M, C = grad_out.shape
+        rc = _lib.lib().pn_scatter_max_grad(_lib.ptr(grad_out), _lib.ptr(arg), M, C, _lib.ptr(grad_src),
+                                            _lib.current_stream(grad_out.device))
+        _lib.check(rc, "pn_scatter_max_grad")
+        return 1
+
+
+def _cuda_i32(t, what):
+    if t.device.type != "cuda":
+        raise _lib.PillarnetHipError(f"{what}: tensor must live on the GPU (no CPU fallback)")
+    return t.contiguous()
+
+
+class ScatterMaxFunction(torch.autograd.Function):
+    """scatter_utils.py:7-35.  `arg` ties resolve to the lowest point index (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, src, index, M):
+        src, index = _cuda_i32(src, "scatter_max").float(), _cuda_i32(index, "scatter_max").int()
+        L, C = src.shape
+        arg = index.new_full((M, C), -1)
+        out = src.new_zeros(M, C)
+        pillar_cuda.scatter_max_wrapper(index, src, arg, out)
+        ctx.for_backwards = (L, C, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L, C, arg = ctx.for_backwards
+        grad_src = grad_out.new_zeros(L, C)
+        pillar_cuda.scatter_max_grad_wrapper(grad_out.contiguous(), arg, grad_src)
+        return grad_src, None, None
+
+
+scatter_max = ScatterMaxFunction.apply
+
+
+def gather_indice(indices, index):
+    """group_utils.py:6-13: outs[i] = indices[index[i]]."""
+    outs = indices.new_zeros((index.shape[0],))
+    pillar_cuda.gather_indice_wrapper(_cuda_i32(index, "gather_indice"), _cuda_i32(indices, "gather_indice"), outs)
+    return outs
+
+
+def gather_feature(features, index):
+    """group_utils.py:16-38 forward (the reference detaches its only input, pillar_modules.py:71)."""
+    outs = features.new_zeros((index.shape[0], features.shape[1]))
+    pillar_cuda.gather_feature_wrapper(_cuda_i32(index, "gather_feature"), _cuda_i32(features, "gather_feature"), outs)
+    return outs
+
+
+def query_and_group(groups: PillarQueryAndGroup, pts_xy, pts_batch_cnt, pts_features):
+    """PillarQueryAndGroup.forward (pillar_utils.py:22-58), unfused, with the reference's own flow:
+    bool mask -> cumsum -> position map -> (b,y,x) rows -> per-point pillar id -> centre offsets."""
+    batch = pts_batch_cnt.numel()
+    H, W = groups.spatial_shape
+    n = pts_xy.shape[0]
+    ppi_flat = pts_batch_cnt.new_full((n,), -1)
+    mask = torch.zeros((batch, H, W), dtype=torch.bool, device=pts_xy.device)
+    pillar_cuda.create_point_pillar_index_stack_wrapper(pts_xy.contiguous(), pts_batch_cnt, mask, ppi_flat)
+    pos = torch.cumsum(mask.view(-1), dim=0, dtype=torch.int32)
+    out_dim = int(pos[-1].item())
+    pos = (pos.view(batch, H, W) * mask - 1).contiguous()
+    pillar_indices = pts_batch_cnt.new_zeros((out_dim, 3))
+    pillar_cuda.create_pillar_indices_wrapper(pos, pillar_indices)
+    point_pillar_indices = gather_indice(pos.view(-1), ppi_flat)
+    centers = torch.stack((pillar_indices[:, 2] * groups.pillar_size + groups.x_offset,
+                           pillar_indices[:, 1] * groups.pillar_size + groups.y_offset), dim=1)
+    ctr = gather_feature(centers, point_pillar_indices)
+    feats = torch.cat([pts_features[:, :2] - ctr, pts_features], dim=1)
+    return pillar_indices, point_pillar_indices, feats
+
+
+def _pmp_forward_unfused(self, pts_xy, pts_batch_cnt, pts_feature):
+    """PillarMaxPooling.forward with the reference's signature (pillar_modules.py:56-74): differentiable
+    w.r.t. the MLP parameters, BatchNorm in whatever mode the module is in."""
+    batch = pts_batch_cnt.shape[0]
+    pillar_indices, ppi, feats = query_and_group(self.groups, pts_xy, pts_batch_cnt, pts_feature)
+    y = self.shared_mlps(feats.detach())
+    pooled = scatter_max(y, ppi, pillar_indices.shape[0])
+    return SparseConvTensor(pooled, pillar_indices, (self.height, self.width), batch)
+
+
+PillarMaxPooling.forward_unfused = _pmp_forward_unfused

@@ -24,4 +24,19 @@ class DynamicPFE(nn.Module):
         self.height, self.width = self.pfn_layers.height, self.pfn_layers.width
 
     def forward(self, data, **kwargs):
-        return self.pfn_layers(list(data["points"]))
+        if not self.training:
+            return self.pfn_layers(list(data["points"]))
+        # training: the reference's own sequence (dynamic_pillar_encoder.py:30-50) on torch ops, then the
+        # unfused, differentiable PillarMaxPooling
+        import torch
+        xy, cnt, feats = [], [], []
+        for points in data["points"]:
+            cx = ((points[:, 0] - self.pc_range[0]) / self.pillar_size).floor().int()
+            cy = ((points[:, 1] - self.pc_range[1]) / self.pillar_size).floor().int()
+            m = (cx >= 0) & (cx < self.width) & (cy >= 0) & (cy < self.height)
+            xy.append(torch.stack((cx[m], cy[m]), dim=1))
+            feats.append(points[m])
+            cnt.append(int(m.sum()))
+        xy = torch.cat(xy)
+        cnt = xy.new_tensor(cnt, dtype=torch.int32)
+        return self.pfn_layers.forward_unfused(xy, cnt, torch.cat(feats))

@@ -163,11 +163,115 @@ def _down_rules(x: SparseConvTensor, stride, pad):
     return out_idx, out_num, out_bits, out_rank, nbr, (Ho, Wo), out_cap
 
 
+class SparseConvFunction(torch.autograd.Function):
+    """Differentiable sparse conv on exact fp32 rows.  Forward and data gradient run the HIP
+    implicit GEMM (the gradient is the same gather-GEMM over the INVERSE rulebook with transposed
+    tap matrices); the weight gradient is nine small torch GEMMs over gathered rows."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, nbr, n_out, inv, count_in, count_out):
+        cout, cin = weight.shape[0], weight.shape[3]
+        dev = feats.device
+        w = weight.detach().permute(1, 2, 0, 3).reshape(9, cout, cin).contiguous().float()
+        ones = torch.ones(cout, device=dev)
+        shift = bias.detach().float().contiguous() if bias is not None else torch.zeros(cout, device=dev)
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+        if n_out > 0:
+            rc = _lib.lib().pn_spconv_forward(_lib.PN_DTYPE_F32, _lib.ptr(feats), cin, feats.shape[0], _lib.ptr(nbr),
+                                              nbr.shape[1], _lib.ptr(count_out), n_out, _lib.ptr(w), _lib.ptr(ones),
+                                              _lib.ptr(shift), None, 0, _lib.ptr(out), cout,
+                                              _lib.current_stream(dev))
+            _lib.check(rc, "pn_spconv_forward")
+        ctx.save_for_backward(feats, weight, nbr, inv, count_in)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, weight, nbr, inv, count_in = ctx.saved_tensors
+        g = g.contiguous().float()
+        cout, cin = weight.shape[0], weight.shape[3]
+        dev = g.device
+        n_in, n_out = feats.shape[0], g.shape[0]
+        grad_feats = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_feats = torch.zeros((n_in, cin), dtype=torch.float32, device=dev)
+            if n_in > 0 and n_out > 0:
+                wd = weight.detach().permute(1, 2, 3, 0).reshape(9, cin, cout).contiguous().float()   # W_k^T
+                ones, zeros = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+                rc = _lib.lib().pn_spconv_forward(_lib.PN_DTYPE_F32, _lib.ptr(g), cout, n_out, _lib.ptr(inv),
+                                                  inv.shape[1], _lib.ptr(count_in), n_in, _lib.ptr(wd),
+                                                  _lib.ptr(ones), _lib.ptr(zeros), None, 0, _lib.ptr(grad_feats),
+                                                  cin, _lib.current_stream(dev))
+                _lib.check(rc, "pn_spconv_forward (data gradient)")
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros((9, cout, cin), dtype=torch.float32, device=dev)
+            for k in range(9):
+                idx = nbr[k, :n_out].long()
+                valid = idx >= 0
+                if valid.any():
+                    gw[k] = g[valid].t() @ feats[idx[valid]]
+            grad_w = gw.view(3, 3, cout, cin).permute(2, 0, 1, 3).contiguous().to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = g.sum(0)
+        return grad_feats, grad_w, grad_b, None, None, None, None, None
+
+
+def _conv_forward_train(x: SparseConvTensor, conv: SparseConvolution):
+    """Training-mode conv (no folding): exact fp32 rows in, exact rows out, autograd-connected."""
+    x = x.exact()
+    feats = x.features_cap
+    if feats.dtype != torch.float32:
+        raise NotImplementedError("training runs in fp32")
+    dev = feats.device
+    n_in = feats.shape[0]
+    if conv.subm:
+        nbr = _subm_rules(x, conv.indice_key)
+        inv = nbr.flip(0).contiguous()        # inv_k = nbr_{8-k} for a submanifold conv
+        out = SparseConvFunction.apply(feats, conv.weight, conv.bias, nbr, n_in, inv, x.num_active, x.num_active)
+        return x.replace_feature(out)
+    out_idx, out_num, out_bits, out_rank, nbr, shape, out_cap = _down_rules(x, conv.stride, conv.padding)
+    n_out = int(out_num.item())
+    nbr = nbr[:, :n_out].contiguous() if n_out else nbr[:, :1].contiguous()
+    inv = torch.empty((9, max(n_in, 1)), dtype=torch.int32, device=dev)
+    rc = _lib.lib().pn_spconv_invert_rules(_lib.ptr(nbr), nbr.shape[1], _lib.ptr(out_num), max(n_out, 1),
+                                           _lib.ptr(inv), inv.shape[1], _lib.current_stream(dev))
+    _lib.check(rc, "pn_spconv_invert_rules")
+    out = SparseConvFunction.apply(feats, conv.weight, conv.bias, nbr, n_out, inv, x.num_active, out_num)
+    y = SparseConvTensor(out, out_idx[:n_out].contiguous(), shape, x.batch_size, out_num, out_bits, out_rank)
+    y._n_host = n_out
+    return y
+
+
+class ToDenseFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, x):
+        ctx.idx = x.indices_cap[: feats.shape[0]].long()
+        return to_dense(x.replace_feature(feats), channels_last=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        i = ctx.idx
+        return g[i[:, 0], :, i[:, 1], i[:, 2]].contiguous(), None
+
+
 def conv_forward(x: SparseConvTensor, conv: SparseConvolution, bn=None, relu=False, residual=None):
-    """conv (+ folded eval-mode norm) (+ residual rows) (+ ReLU) as one kernel."""
+    """conv (+ folded eval-mode norm) (+ residual rows) (+ ReLU) as one kernel; in training mode the
+    plain differentiable conv (the norm / activation then run as torch ops on the rows)."""
     feats = x.features_cap
     if conv.training or (bn is not None and bn.training):
-        raise NotImplementedError("training-mode sparse conv / BatchNorm is not built yet; call .eval()")
+        if feats.device.type != "cuda":
+            raise _lib.PillarnetHipError("sparse conv: features must live on the GPU (no CPU fallback)")
+        y = _conv_forward_train(x, conv)
+        f = y.features_cap
+        if bn is not None:
+            f = bn(f)
+        if residual is not None:
+            r = residual.features_cap if isinstance(residual, SparseConvTensor) else residual
+            f = f + r[: f.shape[0]]
+        if relu:
+            f = torch.relu(f)
+        return y.replace_feature(f) if f is not y.features_cap else y
     if feats.device.type != "cuda":
         raise _lib.PillarnetHipError("sparse conv: features must live on the GPU (no CPU fallback)")
     dt = _dtype_code(feats)

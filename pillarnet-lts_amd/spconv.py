@@ -83,6 +83,17 @@ class SparseConvTensor:
     def indices(self):
         return self.indices_cap[: self.num_active_host()]
 
+    def exact(self):
+        """Same tensor with capacity == active rows (one host sync); the training path works on
+        exact tensors so that BatchNorm statistics and autograd see only real rows."""
+        n = self.num_active_host()
+        if n == self.capacity:
+            return self
+        out = SparseConvTensor(self.features_cap[:n], self.indices_cap[:n].contiguous(), self.spatial_shape,
+                               self.batch_size, self.num_active, self._occ_bits, self._occ_rank, self._keepalive)
+        out._n_host = n
+        return out
+
     def replace_feature(self, new_features):
         """spconv 2.x `replace_feature` (used at base.py:9-10): same sites, new feature rows."""
         if new_features.shape[0] != self.capacity:
@@ -102,4 +113,8 @@ class SparseConvTensor:
         format is channels-last (each active row lands as one contiguous C-vector, and the MIOpen
         convs downstream want NHWC)."""
         from . import sparse_conv
+        if self.features_cap.requires_grad:
+            assert out_channels is None
+            x = self.exact()
+            return sparse_conv.ToDenseFunction.apply(x.features_cap, x)
         return sparse_conv.to_dense(self, channels_last=channels_last, out_channels=out_channels)

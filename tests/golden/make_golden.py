@@ -313,6 +313,91 @@ def golden_reader():
     save("reader.npz", **arrays)
 
 
+def golden_train(head):
+    """Losses, CenterHead.loss, gaussian targets and the one-cycle schedule from the reference."""
+    from det3d.models.losses.centernet_loss import FastFocalLoss, RegLoss, IouRegLoss
+    from det3d.core.utils.center_utils import gaussian_radius, draw_umich_gaussian
+    from det3d.solver.learning_schedules_fastai import OneCycle
+    from det3d.torchie import Config
+    rng = np.random.default_rng(3)
+    arrays = {}
+    # gaussian helpers
+    sizes = rng.uniform(0.5, 30, (20, 2))
+    arrays["gr.sizes"] = sizes
+    arrays["gr.r01"] = np.array([gaussian_radius((a, b), 0.1) for a, b in sizes])
+    arrays["gr.r05"] = np.array([gaussian_radius((a, b), 0.5) for a, b in sizes])
+    hm = np.zeros((40, 50), np.float32)
+    for (x, y, r) in [(5.3, 7.9, 2), (48.2, 38.5, 4), (0.1, 0.2, 3), (25.0, 20.0, 6)]:
+        draw_umich_gaussian(hm, np.array([x, y], np.float32), r)
+    arrays["gauss.hm"] = hm
+    # AssignLabel on a synthetic annotation set
+    # import ONLY preprocess.py: the dataset packages' __init__ files pull nuscenes-devkit / waymo TF
+    for pkg in ("det3d.datasets", "det3d.datasets.pipelines"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules.setdefault(pkg, m)
+    from det3d.datasets.pipelines.preprocess import AssignLabel
+    tasks = [dict(stride=8, class_names=["car"]), dict(stride=8, class_names=["bus", "trailer"])]
+    acfg = Config(dict(target_assigner=dict(tasks=tasks), dense_reg=1, gaussian_overlap=0.1, max_objs=50, min_radius=2,
+                       pc_range=[-6, -4.8, -5.0, 6, 4.8, 3.0], pillar_size=0.075))._cfg_dict
+    al = AssignLabel(cfg=acfg)
+    G = 14
+    boxes = np.zeros((G, 9), np.float32)
+    boxes[:, 0] = rng.uniform(-6.5, 6.5, G); boxes[:, 1] = rng.uniform(-5, 5, G); boxes[:, 2] = rng.normal(-1, .5, G)
+    boxes[:, 3:6] = np.exp(rng.normal(np.log([1.9, 4.5, 1.6]), 0.25, (G, 3)))
+    boxes[:, 6:8] = rng.normal(0, 1, (G, 2)); boxes[:, 8] = rng.uniform(-2 * np.pi, 2 * np.pi, G)
+    classes = rng.integers(1, 4, G)
+    names = np.array([["car", "bus", "trailer"][c - 1] for c in classes])
+    res = {"type": "NuScenesDataset", "lidar": {"annotations": {"gt_boxes": boxes.copy(), "gt_classes": classes.copy(),
+                                                              "gt_names": names}}}
+    out, _ = al(res, None)
+    tg = out["lidar"]["targets"]
+    arrays["al.boxes"], arrays["al.classes"] = boxes, classes
+    for key in ("hm", "anno_box", "ind", "mask", "cat", "gt_box"):
+        for t in range(2):
+            arrays[f"al.{key}.{t}"] = np.asarray(tg[key][t])
+    # losses
+    torch.manual_seed(5)
+    B, H, W, K = 2, 16, 20, 50
+    out_hm = torch.clamp(torch.sigmoid(torch.randn(B, H, W, 2)), 1e-4, 1 - 1e-4)
+    tgt_hm = torch.rand(B, H, W, 2) ** 4
+    ind = torch.randint(0, H * W, (B, K)); mask = (torch.rand(B, K) > 0.6).to(torch.uint8); cat = torch.randint(0, 2, (B, K))
+    arrays.update({"fl.out": out_hm.numpy(), "fl.target": tgt_hm.numpy(), "fl.ind": ind.numpy(), "fl.mask": mask.numpy(),
+                   "fl.cat": cat.numpy(), "fl.loss": FastFocalLoss()(out_hm, tgt_hm, ind, mask, cat).numpy()})
+    reg_out, reg_tgt = torch.randn(B, H, W, 10), torch.randn(B, K, 10)
+    arrays.update({"rl.out": reg_out.numpy(), "rl.target": reg_tgt.numpy(), "rl.loss": RegLoss()(reg_out, mask, ind, reg_tgt).numpy()})
+    bp = torch.randn(B, H, W, 7); bp[..., 3:6] = bp[..., 3:6].abs() + 0.5
+    bg = torch.randn(B, K, 7); bg[..., 3:6] = bg[..., 3:6].abs() + 0.5
+    arrays.update({"il.pred": bp.numpy(), "il.gt": bg.numpy()})
+    for kind in ("IoU", "GIoU", "DIoU"):
+        arrays[f"il.{kind}"] = IouRegLoss(kind)(bp, mask, ind, bg).numpy()
+    # CenterHead.loss on the golden head (2 tasks, vel, GIoU)
+    x = torch.randn(2, 24, 16, 20)
+    head.eval()
+    with torch.no_grad():
+        preds = head((x,))
+    ex = {}
+    for key in ("hm", "anno_box", "ind", "mask", "cat", "gt_box"):
+        ex[key] = [torch.from_numpy(np.stack([arrays[f"al.{key}.{t}"]] * 2)) for t in range(2)]
+    train_cfg = Config(dict(hm_weight=1, bbox_weight=0.25, iou_weight=1, reg_iou_weight=0.25))._cfg_dict
+    ls = head.loss(ex, [{k: v.clone() for k, v in pd.items()} for pd in preds], train_cfg)
+    arrays["hl.x"] = x.numpy()
+    for k, v in ls.items():
+        for t, val in enumerate(v):
+            arrays[f"hl.{k}.{t}"] = np.asarray(val.detach().numpy() if hasattr(val, "detach") else val)
+    # one-cycle schedule
+    class Opt:
+        lr = mom = None
+    o = Opt()
+    sch = OneCycle(o, 200, 0.001, [0.95, 0.85], 10.0, 0.4)
+    seq = []
+    for step in range(200):
+        sch.step(step)
+        seq.append((o.lr, o.mom))
+    arrays["oc.seq"] = np.asarray(seq)
+    save("train.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is required"
     install_stubs()
@@ -321,3 +406,4 @@ if __name__ == "__main__":
     golden_reader()
     head, preds = golden_dense()
     golden_decode(head, preds)
+    golden_train(head)

@@ -182,7 +182,7 @@ def test_no_cpu_fallback():
     from pillarnet_lts_amd import iou3d_nms
     with pytest.raises(_lib.PillarnetHipError):
         iou3d_nms.boxes_iou_bev(torch.zeros(2, 7), torch.zeros(2, 7))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.PillarnetHipError):
         sparse_conv.SubMConv2d(32, 32, 3, padding=1).train()(x)
 
 

@@ -1,0 +1,118 @@
+"""CPU: the restated training pieces (losses, CenterHead.loss, gaussian targets, one-cycle schedule)
+against outputs of the reference's own code (tests/golden/train.npz, make_golden.py::golden_train),
+plus a world-size-2 gloo run of the gradient all-reduce."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from pillarnet_lts_amd import losses, solver, targets
+from pillarnet_lts_amd.bbox_heads import CenterHead
+from pillarnet_lts_amd.config import ConfigDict
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train.npz"))
+TASKS = [dict(stride=8, class_names=["car"]), dict(stride=8, class_names=["bus", "trailer"])]
+HEADS = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)}
+RANGE = [-6, -4.8, -5.0, 6, 4.8, 3.0]
+
+
+def test_gaussian_helpers():
+    for a, r1, r5 in zip(G["gr.sizes"], G["gr.r01"], G["gr.r05"]):
+        assert abs(targets.gaussian_radius(tuple(a), 0.1) - r1) < 1e-9
+        assert abs(targets.gaussian_radius(tuple(a), 0.5) - r5) < 1e-9
+    hm = np.zeros((40, 50), np.float32)
+    for (x, y, r) in [(5.3, 7.9, 2), (48.2, 38.5, 4), (0.1, 0.2, 3), (25.0, 20.0, 6)]:
+        targets.draw_gaussian(hm, np.array([x, y], np.float32), r)
+    np.testing.assert_array_equal(hm, G["gauss.hm"])
+
+
+def test_assign_labels_matches_reference():
+    out = targets.assign_labels(G["al.boxes"], G["al.classes"], TASKS, RANGE, 0.075, 0.1, 50, 2)
+    for key in ("hm", "anno_box", "ind", "mask", "cat", "gt_box"):
+        for t in range(2):
+            want = G[f"al.{key}.{t}"]
+            got = np.asarray(out[key][t])
+            assert got.shape == want.shape, (key, t)
+            if got.dtype.kind == "f":
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+            else:
+                np.testing.assert_array_equal(got, want)
+    assert sum(int(G[f"al.mask.{t}"].sum()) for t in range(2)) >= 8
+
+
+def _t(k):
+    return torch.from_numpy(G[k])
+
+
+def test_losses_match_reference():
+    ind, mask, cat = _t("fl.ind"), _t("fl.mask"), _t("fl.cat")
+    fl = losses.fast_focal_loss(_t("fl.out"), _t("fl.target"), ind, mask, cat)
+    np.testing.assert_allclose(fl.numpy(), G["fl.loss"], rtol=1e-6)
+    rl = losses.reg_loss(_t("rl.out"), mask, ind, _t("rl.target"))
+    np.testing.assert_allclose(rl.numpy(), G["rl.loss"], rtol=1e-5, atol=1e-7)
+    for kind in ("IoU", "GIoU", "DIoU"):
+        il = losses.iou_reg_loss(_t("il.pred"), mask, ind, _t("il.gt"), kind)
+        np.testing.assert_allclose(il.numpy(), G[f"il.{kind}"], rtol=1e-5)
+    z = torch.zeros_like(mask)
+    assert float(losses.reg_loss(_t("rl.out"), z, ind, _t("rl.target"))) == 0.0
+
+
+def test_center_head_loss_matches_reference():
+    h = np.load(os.path.join(os.path.dirname(__file__), "golden", "dense_head.npz"))
+    head = CenterHead(tasks=[ConfigDict(t) for t in TASKS], in_channels=[24], code_weights=[1.0] * 10,
+                      common_heads=HEADS, share_channel=16, reg_iou="GIoU", pillar_size=0.075, point_cloud_range=RANGE)
+    head.load_state_dict({k[3:]: torch.from_numpy(h[k]) for k in h.files if k.startswith("sd.")})
+    head.eval()
+    with torch.no_grad():
+        preds = head((_t("hl.x"),))
+    ex = {key: [torch.from_numpy(np.stack([G[f"al.{key}.{t}"]] * 2)) for t in range(2)]
+          for key in ("hm", "anno_box", "ind", "mask", "cat", "gt_box")}
+    out = head.loss(ex, preds, dict(hm_weight=1, bbox_weight=0.25, iou_weight=1, reg_iou_weight=0.25))
+    for key in ("loss", "hm_loss", "loc_loss", "loc_loss_elem", "num_positive", "reg_iou_loss"):
+        for t in range(2):
+            np.testing.assert_allclose(np.asarray(out[key][t].detach()), G[f"hl.{key}.{t}"], rtol=2e-5, atol=1e-6)
+
+
+def test_one_cycle_matches_reference():
+    sch = solver.OneCycle(200, 0.001, (0.95, 0.85), 10.0, 0.4)
+    got = np.asarray([sch.at(s) for s in range(200)])
+    np.testing.assert_allclose(got, G["oc.seq"], rtol=1e-12, atol=1e-15)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo")
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 3)
+    x = torch.full((2, 4), float(rank + 1))
+    lin(x).sum().backward()
+    solver.allreduce_grads(lin.parameters())
+    q.put((rank, lin.weight.grad.clone().numpy(), lin.bias.grad.clone().numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_allreduce_grads_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    # rank r's weight grad is 2*(r+1) everywhere -> mean 3; bias grad 2 on both -> 2
+    for _, gw, gb in res:
+        np.testing.assert_allclose(gw, 3.0)
+        np.testing.assert_allclose(gb, 2.0)

@@ -1,0 +1,166 @@
+"""GPU: training path (a13) -- reference-shaped pillar_cuda operators, scatter-max forward/backward,
+sparse-conv data/weight gradients against torch autograd on the masked dense definition, and a
+whole-detector training step."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from oracle import pillar_oracle as po
+from pillarnet_lts_amd import pillar_ops, presets, solver, sparse_conv as sc, synth, targets
+from pillarnet_lts_amd.spconv import SparseConvTensor
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pillar_cuda_surface_matches_oracle(cuda):
+    """The seven reference-shaped operators, chained exactly as PillarQueryAndGroup.forward chains them."""
+    grid = dict(pillar_size=0.5, pc_range=[-8, -8, -3, 8, 8, 1])
+    rng = np.random.default_rng(0)
+    pts = [rng.uniform(-9, 9, (1500, 5)).astype(np.float32), rng.uniform(-9, 9, (700, 5)).astype(np.float32)]
+    xy, cnt, feats = po.dynamic_pfe_select(pts, grid["pc_range"], grid["pillar_size"])
+    want_idx, want_ppi, want_f = po.pillar_query_and_group(xy, cnt, feats, grid["pillar_size"], grid["pc_range"])
+    g = pillar_ops.PillarQueryAndGroup(grid["pillar_size"], grid["pc_range"])
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    idx, ppi, f = pillar_ops.query_and_group(g, t(xy), t(cnt), t(feats))
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+    np.testing.assert_array_equal(ppi.cpu().numpy(), want_ppi)
+    np.testing.assert_allclose(f.cpu().numpy(), want_f, rtol=0, atol=1e-6)
+
+
+def test_scatter_max_forward_backward(cuda):
+    rng = np.random.default_rng(1)
+    L, C, M = 5000, 32, 700
+    src = rng.normal(size=(L, C)).astype(np.float32)
+    idx = rng.integers(0, M - 50, L).astype(np.int32)          # the last 50 pillars stay empty
+    want = po.scatter_max(src, idx, M)
+    s = torch.from_numpy(src).to(cuda).requires_grad_(True)
+    out = pillar_ops.scatter_max(s, torch.from_numpy(idx).to(cuda), M)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    go = torch.from_numpy(rng.normal(size=(M, C)).astype(np.float32)).to(cuda)
+    out.backward(go)
+    g = s.grad.cpu().numpy()
+    # gradient lands on exactly one maximal point per (pillar, channel) with out > 0, nothing elsewhere
+    gsum = np.zeros((M, C), np.float32)
+    np.add.at(gsum, idx, g)
+    np.testing.assert_allclose(gsum, np.where(want > 0, go.cpu().numpy(), 0), rtol=0, atol=0)
+    nz = np.nonzero(g)
+    assert np.all(src[nz] == want[idx[nz[0]], nz[1]])
+    # deterministic argmax: lowest point index among ties
+    src2 = np.ones((6, 32), np.float32)
+    o2 = pillar_ops.scatter_max(torch.from_numpy(src2).to(cuda).requires_grad_(True),
+                                torch.zeros(6, dtype=torch.int32, device=cuda), 1)
+    s2 = torch.from_numpy(src2).to(cuda).requires_grad_(True)
+    pillar_ops.scatter_max(s2, torch.zeros(6, dtype=torch.int32, device=cuda), 1).sum().backward()
+    assert s2.grad[0].sum() == 32 and s2.grad[1:].abs().sum() == 0 and float(o2.sum()) == 32
+
+
+def _dense_reference(feats, idx, B, H, W, weight, bias, subm):
+    """torch-CPU double autograd on the masked dense definition (oracle/sparse_oracle.dense_definition)."""
+    f = torch.from_numpy(feats).double().requires_grad_(True)
+    w = torch.from_numpy(weight).double().requires_grad_(True)
+    b = torch.from_numpy(bias).double().requires_grad_(True) if bias is not None else None
+    i = torch.from_numpy(idx).long()
+    dense = torch.zeros((B, feats.shape[1], H, W), dtype=torch.float64)
+    dense = dense.index_put((i[:, 0], slice(None), i[:, 1], i[:, 2]), f)
+    mask = torch.zeros((B, 1, H, W), dtype=torch.float64)
+    mask[i[:, 0], 0, i[:, 1], i[:, 2]] = 1
+    wk = w.permute(0, 3, 1, 2)
+    if subm:
+        y = Fn.conv2d(dense, wk, b, 1, 1) * mask
+        mo = mask
+    else:
+        mo = (Fn.max_pool2d(mask, 3, 2, 1) > 0).double()
+        y = Fn.conv2d(dense, wk, b, 2, 1) * mo
+    return f, w, b, y, mo
+
+
+@pytest.mark.parametrize("subm,cin,cout", [(True, 32, 32), (True, 64, 64), (False, 32, 64), (False, 64, 128)])
+def test_sparse_conv_gradients(cuda, subm, cin, cout):
+    rng = np.random.default_rng(cin + cout)
+    B, H, W, n = 2, 21, 18, 260
+    cells = np.sort(rng.choice(B * H * W, n, replace=False))
+    idx = np.stack((cells // (H * W), (cells // W) % H, cells % W), 1).astype(np.int32)
+    feats = rng.normal(size=(n, cin)).astype(np.float32)
+    cls = sc.SubMConv2d if subm else sc.SparseConv2d
+    torch.manual_seed(1)
+    conv = cls(cin, cout, 3, stride=1 if subm else 2, padding=1, bias=subm).to(cuda).train()
+    x = SparseConvTensor(torch.from_numpy(feats).to(cuda).requires_grad_(True), torch.from_numpy(idx).to(cuda),
+                         (H, W), B)
+    y = conv(x)
+    f, w, b, yref, mo = _dense_reference(feats, idx, B, H, W, conv.weight.detach().cpu().numpy(),
+                                         conv.bias.detach().cpu().numpy() if subm else None, subm)
+    yi = y.indices.cpu().long()
+    got = y.features
+    want = yref[yi[:, 0], :, yi[:, 1], yi[:, 2]]
+    assert got.shape[0] == int(mo.sum())
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-4)
+    go = torch.from_numpy(rng.normal(size=tuple(got.shape)).astype(np.float32))
+    got.backward(go.to(cuda))
+    want.backward(go.double())
+    np.testing.assert_allclose(x.features_cap.grad.cpu().numpy(), f.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-3)
+    if subm:
+        np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-3)
+
+
+def _small_train_setup(cuda):
+    torch.manual_seed(0)
+    cfg = presets.nusc_pillarnet18()
+    rng = [-12, -12, -5.0, 12, 12, 3.0]
+    cfg.model.reader.pc_range = rng
+    cfg.model.bbox_head.point_cloud_range = rng
+    cfg.train_cfg.assigner.pc_range = rng
+    model = presets.build(cfg).to(cuda).train()
+    samples = [targets.synthetic_example(synth.nusc_sweep(5000, seed=s, r_max=14.0), cfg.model.bbox_head.tasks, rng,
+                                         cfg.pillar_size, n_boxes=25, seed=s, train_cfg=cfg.train_cfg)
+               for s in (1, 2)]
+    return cfg, model, targets.collate(samples, cuda)
+
+
+def test_detector_train_step(cuda):
+    cfg, model, ex = _small_train_setup(cuda)
+    opt = solver.TrueWdAdam(model.parameters(), wd=0.01)
+    sch = solver.OneCycle(20, 1e-3)
+    first, losses = solver.train_step(model, ex, opt, sch, 0)
+    assert np.isfinite(first)
+    assert set(losses) >= {"loss", "hm_loss", "loc_loss", "loc_loss_elem", "num_positive", "reg_iou_loss"}
+    assert len(losses["loss"]) == 6
+    missing = [n for n, p in model.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
+    nonzero = sum(float(p.grad.abs().sum()) > 0 for p in model.parameters())
+    assert nonzero > 0.9 * sum(1 for _ in model.parameters())
+    vals = [first]
+    for step in range(1, 8):
+        v, _ = solver.train_step(model, ex, opt, sch, step)
+        vals.append(v)
+    assert all(np.isfinite(vals))
+    assert min(vals[-3:]) < vals[0], vals       # the same batch gets easier
+    # and the trained weights still run through the inference path
+    model.to_inference(torch.float32)
+    with torch.no_grad():
+        out = model({"points": ex["points"], "metadata": [{}, {}]}, return_loss=False)
+    assert len(out) == 2 and out[0]["box3d_lidar"].shape[1] == 9
+
+
+def test_reader_gradients_match_torch(cuda):
+    """unfused reader: d(loss)/d(PFN weights) equals torch autograd on the oracle's grouping."""
+    cfg, model, ex = _small_train_setup(cuda)
+    reader = model.reader
+    sp = reader({"points": ex["points"]})
+    go = torch.randn_like(sp.features_cap)
+    (sp.features_cap * go).sum().backward()
+    lin = reader.pfn_layers.shared_mlps[0]
+    got = lin.weight.grad.clone()
+    # reference: same grouping from the oracle, MLP + segment max in torch
+    pts = [p.cpu().numpy() for p in ex["points"]]
+    xy, cnt, feats = po.dynamic_pfe_select(pts, cfg.model.reader.pc_range, cfg.pillar_size)
+    idx, ppi, f7 = po.pillar_query_and_group(xy, cnt, feats, cfg.pillar_size, cfg.model.reader.pc_range)
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), idx)
+    lin.weight.grad = None
+    y = reader.pfn_layers.shared_mlps(torch.from_numpy(f7).to(cuda))
+    M = idx.shape[0]
+    ref = torch.zeros((M, 32), device=cuda).scatter_reduce(0, torch.from_numpy(ppi).long().to(cuda)[:, None].expand(-1, 32),
+                                                          y, "amax", include_self=True)
+    (ref * go).sum().backward()
+    torch.testing.assert_close(got, lin.weight.grad, rtol=1e-3, atol=1e-4)
