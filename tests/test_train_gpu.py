@@ -52,7 +52,7 @@ def test_scatter_max_forward_backward(cuda):
                                 torch.zeros(6, dtype=torch.int32, device=cuda), 1)
     s2 = torch.from_numpy(src2).to(cuda).requires_grad_(True)
     pillar_ops.scatter_max(s2, torch.zeros(6, dtype=torch.int32, device=cuda), 1).sum().backward()
-    assert s2.grad[0].sum() == 32 and s2.grad[1:].abs().sum() == 0 and float(o2.sum()) == 32
+    assert float(s2.grad[0].sum()) == 32 and float(s2.grad[1:].abs().sum()) == 0 and float(o2.detach().sum()) == 32
 
 
 def _dense_reference(feats, idx, B, H, W, weight, bias, subm):
@@ -61,8 +61,8 @@ def _dense_reference(feats, idx, B, H, W, weight, bias, subm):
     w = torch.from_numpy(weight).double().requires_grad_(True)
     b = torch.from_numpy(bias).double().requires_grad_(True) if bias is not None else None
     i = torch.from_numpy(idx).long()
-    dense = torch.zeros((B, feats.shape[1], H, W), dtype=torch.float64)
-    dense = dense.index_put((i[:, 0], slice(None), i[:, 1], i[:, 2]), f)
+    dense = torch.zeros((B, H, W, feats.shape[1]), dtype=torch.float64)
+    dense = dense.index_put((i[:, 0], i[:, 1], i[:, 2]), f).permute(0, 3, 1, 2)
     mask = torch.zeros((B, 1, H, W), dtype=torch.float64)
     mask[i[:, 0], 0, i[:, 1], i[:, 2]] = 1
     wk = w.permute(0, 3, 1, 2)
