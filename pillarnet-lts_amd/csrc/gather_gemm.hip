@@ -336,10 +336,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
       if (rl < BM && m < M && n0 + cl < a.cout_total) {
         const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
         const uint2 v = *reinterpret_cast<const uint2*>(et + rl * EROW + cl * 2);
-        // streamed once, consumed by the NEXT launch: keep it out of this launch's L2 working set
-        // (the gathered rows and the weight slices are what must stay resident)
-        __builtin_nontemporal_store(v.x, reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + cl));
-        __builtin_nontemporal_store(v.y, reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + cl) + 1);
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + cl) = v;
       }
     }
   } else {
