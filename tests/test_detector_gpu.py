@@ -259,7 +259,12 @@ def test_degenerate_frames(cuda):
             out = model({"points": [torch.from_numpy(f).to(cuda) for f in frames], "metadata": [None] * 3},
                         return_loss=False)
         assert len(out) == 3
-        # an empty BEV map gives the same (bias-only) head output everywhere: frames 0 and 1 agree exactly
-        assert torch.equal(out[0]["scores"], out[1]["scores"])
+        # an empty BEV map gives the same (bias-only) head output: frames 0 and 1 agree (exactly on the HIP
+        # dense path; MIOpen's fp32 algorithms may differ in the last bits between batch slots)
+        assert out[0]["scores"].shape == out[1]["scores"].shape
+        if dtype == torch.bfloat16:
+            assert torch.equal(out[0]["scores"], out[1]["scores"])
+        else:
+            torch.testing.assert_close(out[0]["scores"], out[1]["scores"], rtol=1e-5, atol=1e-6)
         for d in out:
             assert d["box3d_lidar"].shape[1] == 9 and torch.isfinite(d["box3d_lidar"]).all()
