@@ -268,3 +268,26 @@ def test_degenerate_frames(cuda):
             torch.testing.assert_close(out[0]["scores"], out[1]["scores"], rtol=1e-5, atol=1e-6)
         for d in out:
             assert d["box3d_lidar"].shape[1] == 9 and torch.isfinite(d["box3d_lidar"]).all()
+
+
+def test_waymo_full_size_structure(cuda):
+    """configs[2] at full size: PillarNet-34, 0.1 m pillars (1504^2 grid), 180k points, RPNG, 3 classes with
+    per-class NMS (pre 2048/1024/1024, post 200/150/150) and the IoU head, bf16 HIP path."""
+    torch.manual_seed(0)
+    cfg = presets.waymo_pillarnet34_fpn()
+    model = presets.build(cfg)
+    synth.randomize_bn_(model, seed=1)
+    model.to_inference(torch.bfloat16)
+    pts = torch.from_numpy(synth.waymo_frame(180000, seed=100)).to(cuda)
+    with torch.no_grad():
+        out = model({"points": [pts], "metadata": [None]}, return_loss=False)
+        out2 = model({"points": [pts], "metadata": [None]}, return_loss=False)
+    d = out[0]
+    n = d["box3d_lidar"].shape[0]
+    assert d["box3d_lidar"].shape == (n, 7) and n <= 500 and n > 0
+    assert int(d["label_preds"].max()) <= 2 and (d["scores"] > 0.1).all()
+    lab = d["label_preds"].cpu().numpy()
+    assert np.all(np.diff(lab) >= 0)          # VEHICLE block, then PEDESTRIAN, then CYCLIST
+    for k, cap in enumerate((200, 150, 150)):
+        assert int((lab == k).sum()) <= cap
+    assert torch.equal(d["box3d_lidar"], out2[0]["box3d_lidar"])
