@@ -293,6 +293,21 @@ int pn_scatter_max_grad(const float* grad_out, const int32_t* arg, int M, int C,
 int pn_spconv_invert_rules(const int32_t* nbr, int nbr_stride, const int32_t* out_count_dev,
                            int out_cap, int32_t* inv, int inv_stride, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * RoI pillar pooling of Pillar R-CNN's second stage: a grid x grid lattice over every rotated RoI,
+ * bilinearly interpolated from a channels-last BEV map.
+ * Replaces BEVStrideFeature.get_pooling_points + interpolate_from_bev_features
+ * (det3d/models/second_stage/bev_interpolation.py:236-268), center_to_grid_box2d
+ * (det3d/core/bbox/box_torch_ops.py:220-251) and bilinear_interpolate_torch
+ * (det3d/core/utils/center_utils.py:91-120).
+ * rois [batch, rois_per_sample, roi_dim] fp32 (x,y,z,dx,dy,dz,...,heading = last element);
+ * map [batch, H*W, map_ld] of `dtype`, first C channels used; cell_size = out_stride * pillar_size;
+ * out [batch, rois_per_sample, grid*grid, C] fp32; points (optional) [.., grid*grid, 2] fp32.
+ * ------------------------------------------------------------------------ */
+int pn_roi_grid_pool(int dtype, const float* rois, int roi_dim, int batch, int rois_per_sample,
+                     int grid, const void* map, int map_ld, int H, int W, int C, float x_min,
+                     float y_min, float cell_size, float* out, float* points, pnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,8 @@ SIGNATURES = {
                                c_void_p]),
     "pn_scatter_max_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pn_spconv_invert_rules": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "pn_roi_grid_pool": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -113,7 +113,8 @@ class PillarNet(SingleStageDetector):
         data = dict(points=example["points"], batch_size=len(example["metadata"]))
         bev_features, backbone_features = self.extract_feat(data)
         preds = self.bbox_head(bev_features)
-        detached = [{k: v.detach() for k, v in p.items()} for p in preds]
+        # (the reference's "manual deepcopy"; in inference the packed head output is passed through as is)
+        detached = [{k: v.detach() for k, v in p.items()} for p in preds] if return_loss else preds
         boxes = self.bbox_head.predict(example, detached, self.test_cfg)
         loss = self.bbox_head.loss(example, preds, self.train_cfg) if return_loss else None
         return boxes, bev_features, backbone_features, loss

@@ -11,6 +11,8 @@ Reference code executed here (imported from /root/reference, nothing copied):
   det3d.models.readers.dynamic_pillar_encoder.DynamicPFE.forward (coordinate + mask step, torch-CPU)
   det3d.ops.pillar_ops.pillar_modules.PillarMaxPooling.shared_mlps   -> reader.npz
   det3d/ops/iou3d_nms/src/iou3d_cpu.cpp (compiled, oracle/_ref)      -> iou3d.npz
+  det3d.models.second_stage.BEVStrideFeature, roi_heads.RoIMIXHead, point_heads.PointHead,
+  detectors.pillar_rcnn.PillarRCNN.post_process       -> rcnn.npz
 
 The reference imports packages this image lacks (numba, addict, spconv, torchvision, terminaltables,
 its own un-built CUDA extensions); they are replaced by inert in-process module objects so that the
@@ -398,6 +400,75 @@ def golden_train(head):
     save("train.npz", **arrays)
 
 
+def golden_rcnn():
+    """Pillar R-CNN second stage from the reference's own modules (torch-CPU): BEVStrideFeature
+    (dense lateral), PointHead, RoIMIXHead (mixer ''), PillarRCNN.post_process (unbound)."""
+    from det3d.models.second_stage.bev_interpolation import BEVStrideFeature
+    from det3d.models.roi_heads.roi_mix_head import RoIMIXHead
+    from det3d.models.point_heads.point_head_simple import PointHead
+    from det3d.models.detectors.pillar_rcnn import PillarRCNN
+    from det3d.torchie import Config
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(12)
+    rng, pillar = [-6.4, -4.8, -2.0, 6.4, 4.8, 4.0], 0.1
+    bev = BEVStrideFeature(feature_sources=["conv3"], pillar_size=pillar, pc_range=rng, out_stride=4, grid_size=7,
+                           in_channels=24, share_channels=16,
+                           backbone_channels=dict(conv1=32, conv2=64, conv3=128, conv4=256),
+                           backbone_strides=dict(conv1=1, conv2=2, conv3=4, conv4=8)).eval()
+    randomize_bn(bev, 6)
+    B, R = 2, 12
+    H, W = int(round(9.6 / pillar / 4)), int(round(12.8 / pillar / 4))
+    rois = torch.zeros(B, R, 7)
+    rois[..., 0] = (torch.rand(B, R, generator=g) - 0.5) * 13.2      # some RoIs hang over the map edge
+    rois[..., 1] = (torch.rand(B, R, generator=g) - 0.5) * 10.0
+    rois[..., 2] = torch.randn(B, R, generator=g) * 0.3
+    rois[..., 3:6] = torch.rand(B, R, 3, generator=g) * 4.0 + 0.4
+    rois[..., 6] = (torch.rand(B, R, generator=g) - 0.5) * 6.6
+    rois[1, -3:] = 0                                                 # padded proposals
+    labels = torch.randint(1, 4, (B, R), generator=g)
+    labels[1, -3:] = 0
+    scores = torch.rand(B, R, generator=g)
+    scores[1, -3:] = 0
+    example = dict(rois=rois.clone(), roi_labels=labels, roi_scores=scores, batch_size=B,
+                   bev_feature=torch.randn(B, 24, H, W, generator=g),
+                   backbone_features=dict(conv3=torch.randn(B, 128, H, W, generator=g)),
+                   metadata=[{"token": i} for i in range(B)])
+    arrays = {"in.rois": rois.numpy(), "in.roi_labels": labels.numpy(), "in.roi_scores": scores.numpy(),
+              "in.bev_feature": example["bev_feature"].numpy(), "in.conv3": example["backbone_features"]["conv3"].numpy(),
+              "meta.pc_range": np.asarray(rng), "meta.pillar": np.asarray(pillar)}
+    cfg = Config(dict(CLASS_AGNOSTIC=True, SHARED_FC=[32, 32], CLS_FC=[32, 32], REG_FC=[32, 32], DP_RATIO=0.3,
+                      TARGET_CONFIG=dict(ROI_PER_IMAGE=128, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                         CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.7, CLS_BG_THRESH=0.25,
+                                         CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.5),
+                      LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="L1",
+                                       LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0,
+                                                         code_weights=[1.0] * 7))))._cfg_dict
+    roi = RoIMIXHead(in_channels=16, model_cfg=cfg, code_size=7, mixer_type="", num_patches=49).eval()
+    randomize_bn(roi, 8)
+    with torch.no_grad():
+        roi.reg_layers[-1].weight.mul_(200.0)        # refinements large enough to matter in the check
+    pcfg = Config(dict(CLASS_AGNOSTIC=True, CLS_FC=[32, 32], TARGET_CONFIG=dict(GT_EXTRA_WIDTH=[0.2, 0.2, 0.2]),
+                       LOSS_CONFIG=dict(LOSS_REG="smooth-l1", LOSS_WEIGHTS=dict(point_cls_weight=1.0))))._cfg_dict
+    ph = PointHead(in_channels=16, num_class=1, model_cfg=pcfg).eval()
+    randomize_bn(ph, 9)
+    with torch.no_grad():
+        example = bev(example)
+        arrays["out.roi_features"] = example["roi_features"].numpy()
+        arrays["out.point_coords"] = example["point_coords"].numpy()
+        example = ph(example)
+        arrays["out.point_cls_scores"] = example["point_cls_scores"].numpy()
+        example = roi(example, training=False)
+        arrays["out.batch_cls_preds"] = example["batch_cls_preds"].numpy()
+        arrays["out.batch_box_preds"] = example["batch_box_preds"].numpy()
+        dets = PillarRCNN.post_process(None, example)
+    for i, d in enumerate(dets):
+        for k in ("box3d_lidar", "scores", "label_preds"):
+            arrays[f"det.{i}.{k}"] = d[k].numpy()
+    for tag, m in (("bev", bev), ("roi", roi), ("ph", ph)):
+        arrays.update({f"sd.{tag}." + k: v for k, v in to_np(m.state_dict()).items()})
+    save("rcnn.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is required"
     install_stubs()
@@ -407,3 +478,4 @@ if __name__ == "__main__":
     head, preds = golden_dense()
     golden_decode(head, preds)
     golden_train(head)
+    golden_rcnn()

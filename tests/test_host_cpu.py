@@ -153,6 +153,11 @@ def test_presets_equal_reference_configs():
     assert json.loads(json.dumps(presets.nusc_pillarnet18().test_cfg)) == ref["pillarnet/pillarnet_centerhead_nusc.py"]["test_cfg"]
     got = strip(presets.waymo_pillarnet34_fpn().model)
     assert got == ref["pillarnet/pillarnet34_fpn_centerhead_waymo.py"]["model"]
+    rc = presets.waymo_pillarrcnn_fpn()
+    got = json.loads(json.dumps(rc.model, default=lambda o: None))
+    got["first_stage_cfg"]["neck"].pop("logger", None)
+    assert got == ref["pillarrcnn/pillarrcnn_fpn_centerhead_waymo.py"]["model"]
+    assert json.loads(json.dumps(rc.test_cfg)) == ref["pillarrcnn/pillarrcnn_fpn_centerhead_waymo.py"]["test_cfg"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present")
@@ -167,6 +172,15 @@ def test_reference_live_configs_load_and_build_unchanged():
         assert isinstance(model.test_cfg.nms.nms_pre_max_size, (int, list))
         built += 1
     assert built == 7
+    cfg = P.Config.fromfile(os.path.join(REF_CFG, "pillarrcnn", "pillarrcnn_fpn_centerhead_waymo.py"))
+    model = P.build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert type(model).__name__ == "PillarRCNN" and model.single_det.NMS_POST_MAXSIZE == 500
+    keys = set(model.state_dict())
+    assert {"roi_head.shared_fc_layer.0.weight", "roi_head.reg_layers.7.bias", "point_head.cls_layers.6.bias",
+            "second_stage.0.lat_conv.0.0.weight", "second_stage.0.fusion_conv.0.bias",
+            "single_det.backbone.conv1.0.conv0.0.weight"} <= keys
+    # pillar_rcnn.py:33 registers the first stage's head a second time: checkpoints carry both prefixes
+    assert sum(k.startswith("bbox_head.") for k in keys) == sum(k.startswith("single_det.bbox_head.") for k in keys) > 0
 
 
 def test_no_cpu_fallback():

@@ -148,3 +148,26 @@ def test_pillar_oracle_invariants():
     np.testing.assert_array_equal(r["indices"], r2["indices"])
     np.testing.assert_allclose(r["features"], r2["features"], rtol=0, atol=0)
     assert (r["features"] >= 0).all()
+
+
+def test_rcnn_second_stage_restatement_matches_reference():
+    """BEVStrideFeature / RoIMIXHead / post_process restated in oracle/rcnn_oracle.py vs the
+    reference modules' own outputs (tests/golden/rcnn.npz)."""
+    from oracle import rcnn_oracle as ro
+    g = load("rcnn.npz")
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    rng, pillar = g["meta.pc_range"], float(g["meta.pillar"])
+    fmap = ro.bev_stride_feature(sd, g["in.bev_feature"], [g["in.conv3"]], p="bev")
+    pooled, pts = ro.roi_grid_pool(g["in.rois"], fmap, 7, 4 * pillar, rng[0], rng[1])
+    np.testing.assert_allclose(pts, g["out.point_coords"], atol=2e-6)
+    B, R = g["in.rois"].shape[:2]
+    np.testing.assert_allclose(pooled.reshape(B, R, -1), g["out.roi_features"], atol=2e-4, rtol=1e-4)
+    cls, boxes = ro.roi_head(sd, g["out.roi_features"], g["in.rois"], p="roi")
+    np.testing.assert_allclose(cls, g["out.batch_cls_preds"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(boxes, g["out.batch_box_preds"], atol=1e-4, rtol=1e-4)
+    dets = ro.post_process(g["out.batch_cls_preds"], g["out.batch_box_preds"], g["in.roi_scores"], g["in.roi_labels"])
+    for i, d in enumerate(dets):
+        np.testing.assert_array_equal(d["label_preds"], g[f"det.{i}.label_preds"])
+        np.testing.assert_array_equal(d["box3d_lidar"], g[f"det.{i}.box3d_lidar"])
+        np.testing.assert_allclose(d["scores"], g[f"det.{i}.scores"], atol=1e-6)
+    assert len(dets[1]["scores"]) == R - 3       # the padded proposals are dropped
