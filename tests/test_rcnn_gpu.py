@@ -124,30 +124,38 @@ def test_pillarrcnn_fp32_matches_oracle(cuda, built_rcnn):
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     first_sd = {k[len("single_det."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("single_det.")}
     ex = {"points": [torch.from_numpy(p).to(cuda) for p in pts], "metadata": [{"token": 0}]}
+    seen = {}
+    # one run only (MIOpen's fp32 convolutions are not run-to-run reproducible): capture what the second stage was fed
+    hook = model.second_stage[0].register_forward_pre_hook(lambda m, args: seen.update(args[0]))
     with torch.no_grad():
         out = model(ex, return_loss=False)
-        first, _, _, _ = model.single_det.forward_two_stage(ex, False)
-        filled = model.reorder_first_stage_prediction(first, {})
-    n = first[0]["box3d_lidar"].shape[0]
+    hook.remove()
+    filled, bev_last, feats = seen, seen["bev_feature"], seen["backbone_features"]
+    n = int((filled["roi_labels"][0] > 0).sum())
     assert 10 < n <= 500 and filled["rois"].shape == (1, 500, 7)
     assert int(filled["roi_labels"][0, :n].min()) >= 1 and int(filled["roi_labels"][0, n:].abs().sum()) == 0
-    # oracle: its own first-stage maps, the product's proposals (first-stage NMS parity is test_detector_gpu's job)
-    _, mid = do.pillarnet_forward(first_sd, pts, cfg.model.first_stage_cfg, model.test_cfg, return_intermediates=True)
+    # The oracle's second stage on the product's proposals (first-stage NMS parity is test_detector_gpu's job),
+    # (a) from the product's first-stage maps -- isolates the second stage, tight -- and (b) from the oracle's
+    # own maps, which differ from the product's by up to 1e-3 before the 3136-wide RoI MLP sums them.
     from oracle import sparse_oracle
+    _, mid = do.pillarnet_forward(first_sd, pts, cfg.model.first_stage_cfg, model.test_cfg, return_intermediates=True)
     lv = mid["levels"]["conv3"]
-    conv3 = sparse_oracle.to_dense(lv[0], lv[1], lv[2], 1)
-    fmap = ro.bev_stride_feature(sd, mid["bev"][-1], [conv3])
+    maps = {"product": (bev_last.float().cpu().numpy(), feats["conv3"].dense().float().cpu().numpy(), 2e-4),
+            "oracle": (mid["bev"][-1], sparse_oracle.to_dense(lv[0], lv[1], lv[2], 1), 5e-3)}
     rois = filled["rois"].cpu().numpy()
-    pooled, _ = ro.roi_grid_pool(rois, fmap, 7, 4 * cfg.pillar_size, -12.8, -12.8)
-    cls, boxes = ro.roi_head(sd, pooled.reshape(1, 500, -1), rois)
-    want = ro.post_process(cls, boxes, filled["roi_scores"].cpu().numpy(), filled["roi_labels"].cpu().numpy())[0]
     got = out[0]
     assert got["box3d_lidar"].shape == (n, 7) and got["metadata"] == {"token": 0}
-    np.testing.assert_array_equal(got["label_preds"].cpu().numpy(), want["label_preds"])
-    np.testing.assert_allclose(got["scores"].cpu().numpy(), want["scores"], atol=1e-3)
-    np.testing.assert_allclose(got["box3d_lidar"].cpu().numpy(), want["box3d_lidar"], atol=2e-3, rtol=1e-3)
+    for name, (bev_map, conv3, tol) in maps.items():
+        fmap = ro.bev_stride_feature(sd, np.ascontiguousarray(bev_map), [np.ascontiguousarray(conv3)])
+        pooled, _ = ro.roi_grid_pool(rois, fmap, 7, 4 * cfg.pillar_size, -12.8, -12.8)
+        cls, boxes = ro.roi_head(sd, pooled.reshape(1, 500, -1), rois)
+        want = ro.post_process(cls, boxes, filled["roi_scores"].cpu().numpy(), filled["roi_labels"].cpu().numpy())[0]
+        np.testing.assert_array_equal(got["label_preds"].cpu().numpy(), want["label_preds"])
+        np.testing.assert_allclose(got["scores"].cpu().numpy(), want["scores"], atol=tol, err_msg=name)
+        np.testing.assert_allclose(got["box3d_lidar"].cpu().numpy(), want["box3d_lidar"], atol=4 * tol, rtol=1e-3,
+                                   err_msg=name)
     # the refinement moved the boxes: this is not the first stage echoed back
-    assert np.abs(got["box3d_lidar"].cpu().numpy() - first[0]["box3d_lidar"].cpu().numpy()).max() > 1e-2
+    assert np.abs(got["box3d_lidar"].cpu().numpy() - rois[0, :n]).max() > 1e-2
 
 
 def test_pillarrcnn_training_is_not_built(cuda, built_rcnn):
