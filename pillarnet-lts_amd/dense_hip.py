@@ -167,6 +167,36 @@ class UpStep:
         return Rows(out, x.B, 2 * x.H, 2 * x.W)
 
 
+class PointwiseStep:
+    """1x1 Conv2d, or ConvTranspose2d(k1, s1) (the same map with the weight transposed), [+ BN] [+ ReLU]:
+    a 1-tap GEMM over the pixel rows."""
+
+    def __init__(self, conv, bn, relu):
+        assert conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+        self.cin, self.cout, self.relu = conv.in_channels, conv.out_channels, relu
+        with torch.no_grad():
+            w = conv.weight.detach()[:, :, 0, 0]
+            if isinstance(conv, nn.ConvTranspose2d):
+                w = w.t()                                   # [cin, cout] -> [cout, cin]
+            self.w = w.reshape(1, self.cout, self.cin).to(torch.bfloat16).contiguous()
+            if bn is not None:
+                self.scale, self.shift = fold_batchnorm(bn, conv.bias)
+            else:
+                self.scale = torch.ones(self.cout, device=w.device)
+                self.shift = (conv.bias.detach().float().clone() if conv.bias is not None
+                              else torch.zeros(self.cout, device=w.device))
+
+    def run(self, x: Rows, out=None):
+        assert x.t.shape[1] == self.cin and x.t.dtype == torch.bfloat16
+        rows = x.t.shape[0]
+        if out is None:
+            out = torch.empty((rows, self.cout), dtype=torch.bfloat16, device=x.t.device)
+        assert out.shape == (rows, self.cout) and out.stride(1) == 1
+        _launch(x.t, self.cin, None, 1, rows, self.w, self.scale, self.shift, self.relu, out, out.stride(0),
+                in_ld=x.ld)
+        return Rows(out, x.B, x.H, x.W)
+
+
 def compile_stack(seq):
     """Sequential of [ZeroPad2d(1)] Conv2d / ConvTranspose2d [BatchNorm2d] [ReLU] -> list of steps."""
     mods = list(seq._modules.values()) if hasattr(seq, "_modules") else list(seq)
@@ -189,7 +219,10 @@ def compile_stack(seq):
             bn, j = mods[j], j + 1
         if j < len(mods) and isinstance(mods[j], (nn.ReLU, SparseReLU)):
             relu, j = True, j + 1
-        steps.append(UpStep(m, bn, relu) if isinstance(m, nn.ConvTranspose2d) else ConvStep(m, bn, relu, pad))
+        if m.kernel_size == (1, 1):
+            steps.append(PointwiseStep(m, bn, relu))
+        else:
+            steps.append(UpStep(m, bn, relu) if isinstance(m, nn.ConvTranspose2d) else ConvStep(m, bn, relu, pad))
         pad, i = 0, j
     return steps
 

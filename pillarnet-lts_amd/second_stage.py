@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, builder
+from . import _lib, builder, dense_hip
 from .detectors import BaseDetector
 from .nn_utils import build_norm_layer
 from .registry import DETECTORS, POINT_HEAD, ROI_HEAD, SECOND_STAGE
@@ -21,26 +21,65 @@ _BN2 = dict(type="BN", momentum=0.01, eps=1e-3)
 _BN1 = dict(type="BN1d", eps=1e-3, momentum=0.01)
 
 
-def roi_grid_pool(rois, feature_map, grid, cell_size, x_min, y_min, want_points=True):
-    """rois [B,R,7+], feature_map [B,C,H,W] (any memory format) -> ([B,R,G*G,C] fp32, [B,R,G*G,2])."""
-    if rois.device.type != "cuda":
+def roi_grid_pool_rows(rois, rows, B, H, W, grid, cell_size, x_min, y_min, want_points=True):
+    """rois [B,R,7+]; rows: the feature map as channels-last pixel rows [B*H*W, C] (fp32 or bf16, row stride
+    >= C) -> ([B,R,G*G,C] fp32, [B,R,G*G,2] world xy of the grid points)."""
+    if rois.device.type != "cuda" or rows.device.type != "cuda":
         raise _lib.PillarnetHipError("roi_grid_pool: tensors must live on the GPU (no CPU fallback)")
-    B, C, H, W = feature_map.shape
-    rows = feature_map.permute(0, 2, 3, 1)
-    if not rows.is_contiguous():
-        rows = rows.contiguous()
-    dt = _lib.PN_DTYPE_BF16 if rows.dtype == torch.bfloat16 else _lib.PN_DTYPE_F32
-    if dt == _lib.PN_DTYPE_F32:
+    assert rows.dim() == 2 and rows.stride(1) == 1 and rows.shape[0] == B * H * W and rois.shape[0] == B
+    if rows.dtype not in (torch.bfloat16, torch.float32):
         rows = rows.float()
+    dt = _lib.PN_DTYPE_BF16 if rows.dtype == torch.bfloat16 else _lib.PN_DTYPE_F32
     rois = rois.contiguous().float()
-    R = rois.shape[1]
+    R, C = rois.shape[1], rows.shape[1]
     out = torch.empty((B, R, grid * grid, C), dtype=torch.float32, device=rois.device)
     pts = torch.empty((B, R, grid * grid, 2), dtype=torch.float32, device=rois.device) if want_points else None
-    rc = _lib.lib().pn_roi_grid_pool(dt, _lib.ptr(rois), rois.shape[2], B, R, grid, _lib.ptr(rows), C, H, W, C,
-                                     float(np.float32(x_min)), float(np.float32(y_min)), float(np.float32(cell_size)),
-                                     _lib.ptr(out), _lib.ptr(pts), _lib.current_stream(rois.device))
+    rc = _lib.lib().pn_roi_grid_pool(dt, _lib.ptr(rois), rois.shape[2], B, R, grid, _lib.ptr(rows), rows.stride(0),
+                                     H, W, C, float(np.float32(x_min)), float(np.float32(y_min)),
+                                     float(np.float32(cell_size)), _lib.ptr(out), _lib.ptr(pts),
+                                     _lib.current_stream(rois.device))
     _lib.check(rc, "pn_roi_grid_pool")
     return out, pts
+
+
+def roi_grid_pool(rois, feature_map, grid, cell_size, x_min, y_min, want_points=True):
+    """As roi_grid_pool_rows for a [B,C,H,W] map in any memory format."""
+    if rois.device.type != "cuda":
+        raise _lib.PillarnetHipError("roi_grid_pool: tensors must live on the GPU (no CPU fallback)")
+    r = dense_hip.Rows.from_nchw(feature_map)
+    return roi_grid_pool_rows(rois, r.t, r.B, r.H, r.W, grid, cell_size, x_min, y_min, want_points)
+
+
+class FoldedMLP:
+    """Eval-mode stack of (Conv1d(k=1) | Linear) + BatchNorm1d + ReLU [+ Dropout] ... as plain fp32
+    `relu(x @ W' + b')` launches with the norm folded into W', b'."""
+
+    def __init__(self, layers):
+        mods = [m for m in layers if not isinstance(m, nn.Dropout)]
+        self.steps, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            assert isinstance(m, (nn.Conv1d, nn.Linear)), type(m).__name__
+            w = m.weight.detach().double().reshape(m.weight.shape[0], -1)
+            b = m.bias.detach().double() if m.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64, device=w.device)
+            relu, j = False, i + 1
+            if j < len(mods) and isinstance(mods[j], nn.modules.batchnorm._BatchNorm):
+                bn = mods[j]
+                assert not bn.training
+                sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
+                w, b = w * sc[:, None], (b - bn.running_mean.double()) * sc + bn.bias.detach().double()
+                j += 1
+            if j < len(mods) and isinstance(mods[j], nn.ReLU):
+                relu, j = True, j + 1
+            self.steps.append((w.t().float().contiguous(), b.float().contiguous(), relu))
+            i = j
+
+    def __call__(self, x):
+        for wt, b, relu in self.steps:
+            x = torch.addmm(b, x, wt)
+            if relu:
+                x = torch.relu_(x)
+        return x
 
 
 @SECOND_STAGE.register_module
@@ -80,7 +119,33 @@ class BEVStrideFeature(nn.Module):
                                          nn.ReLU())
         self.out_stride = out_stride
 
+    def _compile(self, _self=None):
+        td = dense_hip.compile_stack(self.top_down_conv)
+        lat = [dense_hip.compile_stack(m) for m in self.lat_conv]
+        return td, lat, dense_hip.compile_stack(self.fusion_conv)
+
+    def fused_rows_hip(self, example):
+        """bf16 on the gather-GEMM: the up/lateral maps land in channel slices of one buffer (no concat),
+        the 3x3 fusion conv + bias + BN + ReLU is one launch.  -> Rows [B*H*W, share_channels] bf16."""
+        td, lat, fusion = dense_hip.PLANS.get(self, self._compile)
+        x = dense_hip.Rows.from_nchw(example["bev_feature"])
+        widths = [td[-1].cout] + [l[-1].cout for l in lat]
+        up = 2 ** sum(isinstance(s, dense_hip.UpStep) for s in td)
+        B, H, W = x.B, x.H * up, x.W * up
+        cat = torch.empty((B * H * W, sum(widths)), dtype=torch.bfloat16, device=x.t.device)
+        dense_hip.run_stack(td, x, cat[:, :widths[0]])
+        c0 = widths[0]
+        for k, src in enumerate(self.lat_conv_name):
+            f = example["backbone_features"][src]
+            if isinstance(f, SparseConvTensor):
+                f = f.dense()
+            dense_hip.run_stack(lat[k], dense_hip.Rows.from_nchw(f.to(torch.bfloat16)), cat[:, c0:c0 + widths[k + 1]])
+            c0 += widths[k + 1]
+        return dense_hip.run_stack(fusion, dense_hip.Rows(cat, B, H, W))
+
     def fused_map(self, example):
+        if getattr(self, "_dense_hip", False) and example["bev_feature"].dtype == torch.bfloat16:
+            return self.fused_rows_hip(example).nchw()
         ref = next(self.parameters())
         cast = lambda t: t if t.dtype == ref.dtype else t.to(ref.dtype)
         feats = [self.top_down_conv(cast(example["bev_feature"]))]
@@ -93,9 +158,10 @@ class BEVStrideFeature(nn.Module):
 
     def forward(self, example):
         B, R = example["rois"].shape[:2]
-        fmap = self.fused_map(example)
-        pooled, pts = roi_grid_pool(example["rois"], fmap, self.grid_size, self.out_stride * self.pillar_size,
-                                    self.point_cloud_range[0], self.point_cloud_range[1])
+        r = dense_hip.Rows.from_nchw(self.fused_map(example))
+        pooled, pts = roi_grid_pool_rows(example["rois"], r.t, r.B, r.H, r.W, self.grid_size,
+                                         self.out_stride * self.pillar_size, self.point_cloud_range[0],
+                                         self.point_cloud_range[1])
         example["roi_features"] = pooled.view(B, R, -1)
         example["point_features"] = pooled
         example["point_coords"] = pts
@@ -169,10 +235,11 @@ class RoIMIXHead(nn.Module):
         feats = self.mlp_mixer(batch_dict["roi_features"].view(B * R, self.num_patches, -1))
         if self.add_box_param:
             feats = torch.cat([feats, batch_dict["rois"], batch_dict["roi_scores"].unsqueeze(-1)], dim=-1)
-        x = self.shared_fc_layer(feats.reshape(B * R, -1, 1).to(next(self.parameters()).dtype))
-        cls = self.cls_layers(x).transpose(1, 2).contiguous().squeeze(dim=1)
-        reg = self.reg_layers(x).transpose(1, 2).contiguous().squeeze(dim=1)
-        c, b = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"], cls.float(), reg.float())
+        shared, cls_mlp, reg_mlp = dense_hip.PLANS.get(self, lambda m: (
+            FoldedMLP(m.shared_fc_layer), FoldedMLP(m.cls_layers), FoldedMLP(m.reg_layers)))
+        x = shared(feats.reshape(B * R, -1).float())
+        cls, reg = cls_mlp(x), reg_mlp(x)
+        c, b = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"], cls, reg)
         batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"] = c, b
         batch_dict["cls_preds_normalized"] = False
         return batch_dict
@@ -196,8 +263,8 @@ class PointHead(nn.Module):
         if self.training:
             raise NotImplementedError("point-head target assignment / loss is not built")
         pf = batch_dict["point_features"]
-        preds = self.cls_layers(pf.view(-1, pf.shape[-1]).to(next(self.parameters()).dtype))
-        batch_dict["point_cls_scores"] = torch.sigmoid(preds.float())
+        mlp = dense_hip.PLANS.get(self, lambda m: FoldedMLP(m.cls_layers))
+        batch_dict["point_cls_scores"] = torch.sigmoid(mlp(pf.reshape(-1, pf.shape[-1]).float()))
         if self.model_cfg.get("ATT_MODEL", False):
             batch_dict["point_features"] = pf * batch_dict["point_cls_scores"].view(*pf.shape[:-1], 1)
         return batch_dict
@@ -231,7 +298,9 @@ class PillarRCNN(BaseDetector):
         self.eval().to(device)
         for m in list(self.second_stage) + [self.point_head, self.roi_head]:
             if m is not None:
-                m.float()      # small: 41 GFLOP fusion conv + RoI MLPs, kept in fp32 on PyTorch-ROCm
+                m.float()      # parameters stay fp32; the RoI MLPs (< 2 GFLOP) run in fp32
+        for m in self.second_stage:
+            m._dense_hip = dtype == torch.bfloat16 and dense_backend == "hip"   # map fusion on the bf16 gather-GEMM
         return self
 
     def reorder_first_stage_prediction(self, first_pred, example):
@@ -272,7 +341,7 @@ class PillarRCNN(BaseDetector):
             if box.shape[-1] == 9:
                 box = box[:, [0, 1, 2, 3, 4, 5, 7, 8, 6]]
             score = torch.sqrt(torch.sigmoid(cls).view(-1) * batch_dict["roi_scores"][i].view(-1))
-            m = (lab != 0).view(-1) & (box[:, 3:6] > 0).all(1)
-            out.append({"box3d_lidar": box[m, :], "scores": score[m], "label_preds": lab[m] - 1,
-                        "metadata": batch_dict["metadata"][i]})
+            keep = ((lab != 0).view(-1) & (box[:, 3:6] > 0).all(1)).nonzero().view(-1)   # one host sync per sample
+            out.append({"box3d_lidar": box.index_select(0, keep), "scores": score.index_select(0, keep),
+                        "label_preds": lab.index_select(0, keep) - 1, "metadata": batch_dict["metadata"][i]})
         return out

@@ -180,3 +180,24 @@ def test_pillarrcnn_full_size_bf16(cuda):
     assert torch.isfinite(d["box3d_lidar"]).all() and ((d["scores"] >= 0) & (d["scores"] <= 1)).all()
     assert int(d["label_preds"].min()) >= 0 and int(d["label_preds"].max()) <= 2
     assert torch.equal(d["label_preds"], out2[0]["label_preds"])
+
+
+def test_fused_map_bf16_gather_gemm_close_to_fp32_modules(cuda, built_rcnn):
+    """The bf16 HIP map fusion (1-tap GEMMs into channel slices + one 3x3 launch) against the torch modules in fp32."""
+    _, model, _ = built_rcnn
+    model.to_inference(torch.float32)
+    bsf = model.second_stage[0]
+    g = torch.Generator().manual_seed(5)
+    bev = torch.randn(2, 128, 20, 28, generator=g).to(cuda)
+    c3 = (torch.randn(2, 128, 20, 28, generator=g) * (torch.rand(2, 1, 20, 28, generator=g) < 0.3)).to(cuda)
+    ex = dict(bev_feature=bev.to(torch.bfloat16).float(), backbone_features=dict(conv3=c3.to(torch.bfloat16).float()))
+    with torch.no_grad():
+        bsf._dense_hip = False
+        want = bsf.fused_map(ex)
+        bsf._dense_hip = True
+        got = bsf.fused_map(dict(bev_feature=bev.to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
+                                 backbone_features=dict(conv3=c3.to(torch.bfloat16))))
+        bsf._dense_hip = False
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape
+    rel = (got.float() - want).norm() / want.norm()
+    assert rel < 1e-2, float(rel)
