@@ -20,58 +20,26 @@
 //     with a row stride and channel offset so "concat" never materialises.
 //   * Weights are re-read from L2 once per workgroup, not once per wavefront as in the first
 //     kernel (spconv.hip), which was what bounded it at ~7 % of the MFMA peak.
-#include "common.h"
+#include "gg_common.h"
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+// diag == 3: wave 0 of the first workgroups stamps s_memtime at the phase boundaries of every stage
+// (read back with pn_gg_debug_stamps; a tuning aid, not part of the public header)
+static constexpr int GG_STAMP_WG = 4, GG_STAMP_STAGES = 40, GG_STAMP_PER = 6;
+__device__ unsigned long long gg_stamps[GG_STAMP_WG * GG_STAMP_STAGES * GG_STAMP_PER];
+#define GG_STAMP(slot)                                                                                  \
+  do {                                                                                                  \
+    if (a.diag == 3 && wave == 0 && blockIdx.x < GG_STAMP_WG && s < GG_STAMP_STAGES && blockIdx.y == 0) { \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
+      if (lane == 0) gg_stamps[(blockIdx.x * GG_STAMP_STAGES + s) * GG_STAMP_PER + (slot)] = t_;         \
+    }                                                                                                   \
+  } while (0)
 
-template <int BK> __device__ __forceinline__ int swz(int row);
-template <> __device__ __forceinline__ int swz<64>(int row) { return (row >> 1) & 7; }  // 8 chunks / row
-template <> __device__ __forceinline__ int swz<32>(int row) { return (row >> 2) & 3; }  // 4 chunks / row
-
-template <typename TOut> struct OutOps;
-template <> struct OutOps<__bf16> {
-  static __device__ __forceinline__ void store4(__bf16* p, f32x4 v) {
-    bf16x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-    *reinterpret_cast<bf16x4*>(p) = o;
-  }
-};
-template <> struct OutOps<float> {
-  static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-};
-
-struct GGArgs {
-  const __bf16* in;        // [*, in_ld] rows, the first cin channels are used
-  int in_ld;
-  unsigned in_bytes;       // extent of `in` for the buffer descriptor of the LDS-DMA path (0: use register staging)
-  const int32_t* nbr;      // [ntaps][nbr_stride] input row per (tap, output site) or -1; NULL: identity (ntaps == 1)
-  int nbr_stride;
-  const int32_t* count;    // device row count (NULL: rows)
-  int rows;                // capacity / host row count
-  const __bf16* wt;        // [ntaps][cout_total][cin]
-  int cin, cout_total, ntaps;
-  const float* scale;      // [cout_total]
-  const float* shift;
-  const __bf16* residual;  // [rows, res_ld] or NULL
-  int res_ld;
-  int relu;
-  void* out;               // [*, out_ld] rows, channel offset already applied by the caller
-  int out_ld;
-  const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
-  // grouped launch (blockIdx.z = group g): element offsets added per group
-  long long g_in, g_wt, g_ss, g_out;
-  int diag;                // 1: skip LDS reads + MFMAs (staging-rate probe), 2: skip staging (math-rate probe)
-};
-
-// out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
-// missing neighbour (or a weight row past cout) becomes a zero LDS row on the LDS-DMA path
-static constexpr unsigned GG_OOB = 0x80000000u;
-static constexpr int GG_MAX_TAPS = 9;
+extern "C" int pn_gg_debug_stamps(unsigned long long* host_out, int n) {
+  const int total = GG_STAMP_WG * GG_STAMP_STAGES * GG_STAMP_PER;
+  if (n > total) n = total;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gg_stamps), (size_t)n * 8);
+}
 
 template <int BM, int BN, int NWM, int NWN, int BK, typename TOut, bool DMA, int NBUF>
 __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
@@ -243,11 +211,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   __syncthreads();
 
   for (int s = 0; s < stages; ++s) {
+    GG_STAMP(0);
     if constexpr (DMA) {
       if (s + NBUF - 1 < stages && a.diag != 2) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
     } else {
       if (s + 1 < stages) issue(s + 1);
     }
+    GG_STAMP(1);
     const char* abase = smem + (s % NBUF) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
     if (a.diag != 1)
@@ -271,13 +241,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     }
+    GG_STAMP(2);
     if constexpr (DMA && NBUF == 3) {
       // stage s+1 must have landed; stage s+2 (if issued) may stay in flight
       if (s + 2 < stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PIECES_PER_WAVE) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else if constexpr (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GG_STAMP(3);
       __syncthreads();
+      GG_STAMP(4);
     } else {
       if (s + 1 < stages) commit((s + 1) & 1);
       __syncthreads();
@@ -457,6 +430,10 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.g_in = a.g_wt = a.g_ss = a.g_out = 0;
   { const char* d = getenv("PN_GG_DIAG"); a.diag = d ? atoi(d) : 0; }
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
+  {
+    const int rc = pn_gg_try_window(a, 1, out_fp32 != 0, stream);   // 3x3 rulebooks: window-staged kernel
+    if (rc != -1) return rc;
+  }
   return out_fp32 ? dispatch_gg<float>(a, 1, stream) : dispatch_gg<__bf16>(a, 1, stream);
 }
 
@@ -483,6 +460,10 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
   a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;
   a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
   a.diag = 0;
+  {
+    const int rc = pn_gg_try_window(a, groups, out_fp32 != 0, stream);
+    if (rc != -1) return rc;
+  }
   return out_fp32 ? dispatch_gg<float>(a, groups, stream) : dispatch_gg<__bf16>(a, groups, stream);
 }
 

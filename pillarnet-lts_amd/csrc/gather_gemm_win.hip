@@ -1,0 +1,518 @@
+// Window-staged gather -> MFMA implicit GEMM for 3x3 rulebooks (bf16 in, fp32 accumulate), gfx950.
+//
+// Same contract as gather_gemm.hip (out[m] = epilogue(sum_tap W[tap] . in[nbr[tap][m]])), different
+// staging.  Pillar rows are sorted by flat BEV index and a tile is BM *consecutive* output sites, so
+// the input rows that the three taps of one kernel row ky touch -- cells (y+ky-1, x-1..x+1) of every
+// site of the tile -- are one nearly contiguous run [lo, hi] of the input row list (exactly BM+2 rows
+// on a dense grid).  Per (ky, channel chunk) the workgroup therefore copies that run into LDS ONCE, as
+// a linear block (no per-row indices, full 128-B lines), and the three taps kx = 0..2 read their MFMA
+// operand rows out of it through a small per-site row table.  Against staging BM gathered rows per
+// tap this cuts the activation traffic from L2 by ~2.7x (9*BM -> 3*(BM+2) rows per chunk); the
+// per-CU L2 request rate is what bounds the per-tap kernel.
+//
+// Per tile the kernel checks that all three runs fit the window (WMAX rows); a tile where one does
+// not (a rulebook without this locality, or neighbouring image rows much denser than the tile's) is
+// processed by the same pipeline in "gather mode": the window is filled with the BM gathered rows of
+// one tap and the row table is the identity.  Results are identical in both modes.
+//
+// Wave specialisation.  In-kernel s_memtime stamps of the per-tap kernel (scripts/gg_stamps.py) show a
+// wave spending ~1000 of a stage's ~2900 cycles ISSUING its six LDS-DMA pieces (165 cycles each),
+// ~850 on its 16 MFMAs and ~800 waiting (vmcnt + barrier) -- and every wave of a SIMD is in the same
+// phase at the same time.  Here NWC compute waves (one per SIMD, 64 x 128 or 64 x 64 tiles) only read
+// LDS and issue MFMAs, and NWL loader waves only compute addresses and issue DMA: weights run two
+// stages ahead through a 3-deep ring (`s_waitcnt vmcnt(N)` leaves the newest stage in flight), the
+// window one unit ahead.  One `s_barrier` per stage hands buffers between the two roles.
+#include "gg_common.h"
+#include <stdlib.h>
+
+// The loader waves share their SIMD's issue port with the compute waves' MFMAs (a wave64 VALU op holds
+// it for 4 cycles, an MFMA for 8 of its 32): ~30 address instructions per DMA piece -- what the first
+// version of this kernel and the per-tap kernel spend -- cost more issue time than the MFMAs themselves.
+// So everything per-lane is computed ONCE (LoaderLanes) and a piece is `s_mov m0` + one buffer_load whose
+// stage-dependent part of the address travels in the scalar offset operand.
+template <int NPW, int NPA>
+struct LoaderLanes {
+  unsigned w[NPW];   // weight piece j: ((n0 + row) * cin) * 2 + swizzled chunk, or GG_OOB past cout
+  unsigned a[NPA];   // window piece j: row * in_row_bytes + swizzled chunk (row = piece row inside the window)
+  int arow[NPA];     // ... and that row, for the `row < cnt` test of a run's last piece
+};
+
+// Window fill -> `base`.  Window mode: rows lo .. lo+cnt-1 of the input as a linear block (pieces past
+// the run are skipped: stale LDS there is never addressed).  Gather mode (slow path): the BM rows
+// nbr_row[0..BM).  Lane l of a piece fills slot l%CH of row l/CH and fetches chunk (slot ^ swizzle(row))
+// of the source row, so the LDS image stays linear and the MFMA operand reads are bank-conflict free.
+template <int BK, int WMAX, int BM, int NW, int NPW, int NPA>
+__device__ __forceinline__ void win_fill(char* base, __amdgpu_buffer_rsrc_t rs_in, int wave, int lane, bool win,
+                                         int lo, int cnt, int kc, const int* nbr_row, unsigned in_row_bytes,
+                                         const LoaderLanes<NPW, NPA>& L) {
+  constexpr int CH = BK / 8, ROWB = BK * 2, RPP = 1024 / ROWB;
+  if (win) {
+    const unsigned soff = (unsigned)lo * in_row_bytes + (unsigned)(kc * ROWB);   // scalar
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int piece = wave + j * NW;
+      if (piece * RPP >= cnt) break;
+      const unsigned off = L.arow[j] < cnt ? L.a[j] : GG_OOB;
+      auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, soff, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int piece = wave + j * NW;
+      if (piece * RPP >= BM) break;
+      const int row = piece * RPP + lane / CH, slot = lane % CH;
+      const int src = nbr_row[row];
+      const unsigned off = src >= 0 ? (unsigned)src * in_row_bytes + (unsigned)(kc * ROWB) +
+                                          (unsigned)((slot ^ swz<BK>(row)) << 4)
+                                    : GG_OOB;
+      auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, 0, 0, 0);
+    }
+  }
+}
+
+// weight tile (tap, channel chunk kc), BN rows -> `base`: NPW pieces per loader wave, no per-piece VALU
+template <int BK, int BN, int NW, int NPW, int NPA>
+__device__ __forceinline__ void win_wload(char* base, __amdgpu_buffer_rsrc_t rs_wt, int wave, int tap, int kc,
+                                          int cout_total, int cin, const LoaderLanes<NPW, NPA>& L) {
+  constexpr int ROWB = BK * 2;
+  const unsigned soff = (unsigned)(tap * cout_total) * (unsigned)cin * 2u + (unsigned)(kc * ROWB);   // scalar
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int piece = wave + j * NW;
+    auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, lds, 16, L.w[j], soff, 0, 0);
+  }
+}
+
+// diag == 4: s_memtime stamps of workgroup 0 (tuning aid; read with pn_gg_win_debug_stamps):
+// [0..3] kernel start / prologue done / main loop done / end (compute wave 0); then per stage 4 slots:
+// compute wave 0 {stage start, MFMAs done, barrier passed}, loader wave 0 {ready for the barrier};
+// then 8 prologue / epilogue marks
+static constexpr int GGW_STAMP_STAGES = 40;
+__device__ unsigned long long ggw_stamps[4 + GGW_STAMP_STAGES * 4 + 8];
+#define GGW_STAMP(cond, idx)                                                    \
+  do {                                                                          \
+    if (a.diag == 4 && blockIdx.x == 0 && blockIdx.y == 0 && (cond)) {          \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
+      if (lane == 0) ggw_stamps[(idx)] = t_;                                    \
+    }                                                                           \
+  } while (0)
+extern "C" int pn_gg_win_debug_stamps(unsigned long long* host_out, int n) {
+  const int total = 4 + GGW_STAMP_STAGES * 4 + 8;
+  if (n > total) n = total;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ggw_stamps), (size_t)n * 8);
+}
+
+// LDS pool = the staging buffers (2 windows + 3 weight tiles), or the parked fp32 output tile if larger
+template <int BM, int BN, int BK, int WMAX>
+constexpr int win_pool_bytes() {
+  constexpr int RPP = 1024 / (BK * 2);
+  constexpr int staging = 2 * (WMAX + RPP) * BK * 2 + 3 * BN * BK * 2;
+  constexpr int parked = BM * (BN * 4 + 16);
+  return staging > parked ? staging : parked;
+}
+
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut>
+__global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a, int force_gather) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no __amdgpu_buffer_rsrc_t to check the helpers against
+  constexpr int NWC = NWM * NWN;              // compute waves; waves NWC .. NWC+NWL-1 are loaders
+  constexpr int NT = (NWC + NWL) * 64, NW = NT / 64;
+  constexpr int CH = BK / 8;                  // 16-B chunks per LDS row
+  constexpr int ROWB = BK * 2;                // bytes per LDS row
+  constexpr int RPP = 1024 / ROWB;            // rows one wave-wide 16-B DMA instruction lands
+  constexpr int WTM = BM / NWM, WTN = BN / NWN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ABUF = (WMAX + RPP) * ROWB;   // window + one piece of zero rows (row WMAX = "no neighbour")
+  constexpr int WBUF = BN * ROWB;
+  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX>();   // staging buffers; the epilogue parks the fp32 tile here
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
+  static_assert(NWM * NWN + NWL >= 3, "three waves reduce the rulebook tile");
+  static_assert(WMAX % RPP == 0 && BM % RPP == 0 && BN % RPP == 0 && BM <= WMAX, "window geometry");
+  static_assert((BN / RPP) % NWL == 0, "every loader wave must issue the same number of weight pieces");
+  constexpr int NWP = BN / RPP / NWL;         // weight pieces per loader wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wsm = smem + 2 * ABUF;
+  int* const nbr_lds = reinterpret_cast<int*>(smem + POOL);   // [9][BM]
+  int* const meta = nbr_lds + 9 * BM;                          // lo/hi per kernel row (8 ints)
+  float* const sc_lds = reinterpret_cast<float*>(meta + 8);    // [BN] scale, [BN] shift
+
+  {
+    const long long g = blockIdx.z;
+    a.in += g * a.g_in;
+    a.wt += g * a.g_wt;
+    a.scale += g * a.g_ss;
+    a.shift += g * a.g_ss;
+    a.out = reinterpret_cast<char*>(a.out) + g * a.g_out * (long long)sizeof(TOut);
+  }
+  int M = a.count ? *a.count : a.rows;
+  if (M > a.rows) M = a.rows;
+  int bx = blockIdx.x;
+  {  // XCD-contiguous bands of row tiles (see gather_gemm.hip)
+    const int nwg = (M + BM - 1) / BM;
+    if (bx >= nwg) return;
+    const int x = bx & 7, q = nwg >> 3, r = nwg & 7;
+    bx = x * q + (x < r ? x : r) + (bx >> 3);
+  }
+  const int m0 = bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int kchunks = a.cin / BK;
+  const int nstages = 9 * kchunks;             // stage s = (kernel row g, channel chunk kc, kx t), t fastest
+  const bool loader = wave >= NWC;             // wave-uniform role
+  const int lw = wave - NWC;                   // loader index (pieces are dealt round-robin over NWL)
+  GGW_STAMP(wave == 0, 0);
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.wt, 0, (int)((size_t)9 * a.cout_total * a.cin * 2), 0x00020000);
+  const unsigned in_row_bytes = (unsigned)a.in_ld * 2u;
+  constexpr int NPA = (WMAX / RPP + NWL - 1) / NWL;   // window pieces per loader wave
+  LoaderLanes<NWP, NPA> LL;
+  {
+    const int lrow = lane / CH, slot = lane % CH;
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) {
+      const int r = ((loader ? lw : 0) + j * NWL) * RPP + lrow, n = n0 + r;
+      LL.w[j] = n < a.cout_total ? ((unsigned)n * (unsigned)a.cin) * 2u + (unsigned)((slot ^ swz<BK>(r)) << 4) : GG_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int r = ((loader ? lw : 0) + j * NWL) * RPP + lrow;
+      LL.arow[j] = r;
+      LL.a[j] = (unsigned)r * in_row_bytes + (unsigned)((slot ^ swz<BK>(r)) << 4);
+    }
+  }
+#define WIN_WLOAD(s_)                                                                                     \
+  do {                                                                                                    \
+    const int u_ = (s_) / 3, g_ = u_ / kchunks;                                                           \
+    win_wload<BK, BN, NWL, NWP, NPA>(wsm + ((s_) % 3) * WBUF, rs_wt, lw, 3 * g_ + ((s_)-3 * u_),           \
+                                     u_ - g_ * kchunks, a.cout_total, a.cin, LL);                         \
+  } while (0)
+
+  // the weights do not depend on the rulebook: stages 0 and 1 are under way before anything else
+  if (loader) {
+    WIN_WLOAD(0);
+    WIN_WLOAD(1);
+  }
+
+  // ---- rulebook tile -> LDS, run [lo, hi] of every kernel row, zero rows, scale/shift ------------
+  if (tid < 2 * RPP * CH) {   // RPP zero rows in each of the two window buffers
+    const int b = tid / (RPP * CH), q = tid - b * (RPP * CH);
+    *reinterpret_cast<uint4*>(smem + b * ABUF + WMAX * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
+  }
+  int nb[(9 * BM + NT - 1) / NT];
+#pragma unroll
+  for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {   // all loads in flight before the first use
+    const int q = tid + j * NT, tap = q / BM, r = q - tap * BM, m = m0 + r;
+    nb[j] = (q < 9 * BM && m < M) ? a.nbr[(size_t)tap * a.nbr_stride + m] : -1;
+  }
+  float scv = 0.f, shv = 0.f;
+  if (tid < BN && n0 + tid < a.cout_total) {
+    scv = a.scale[n0 + tid];
+    shv = a.shift[n0 + tid];
+  }
+#pragma unroll
+  for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {
+    const int q = tid + j * NT;
+    if (q < 9 * BM) nbr_lds[q] = nb[j];
+  }
+  if (tid < BN) {
+    sc_lds[tid] = scv;
+    sc_lds[BN + tid] = shv;
+  }
+  static_assert(BN <= NT, "one thread per channel stages scale / shift");
+  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt drain: the weight DMA stays in flight)
+  if (wave < 3) {   // wave g reduces kernel row g: entries [3g*BM, 3(g+1)*BM) of the tile
+    int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+    for (int j = 0; j < (3 * BM + 63) / 64; ++j) {
+      const int q = lane + j * 64;
+      if (q < 3 * BM) {
+        const int v = nbr_lds[wave * 3 * BM + q];
+        if (v >= 0) {
+          lo = min(lo, v);
+          hi = max(hi, v);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo = min(lo, __shfl_xor(lo, d));
+      hi = max(hi, __shfl_xor(hi, d));
+    }
+    if (lane == 0) {
+      meta[2 * wave] = lo;
+      meta[2 * wave + 1] = hi;
+    }
+  }
+  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 2);
+  // scalars, not an array: a dynamically indexed array would live in scratch
+  const int h0 = __builtin_amdgcn_readfirstlane(meta[1]), h1 = __builtin_amdgcn_readfirstlane(meta[3]),
+            h2 = __builtin_amdgcn_readfirstlane(meta[5]);
+  const int lo0 = h0 >= 0 ? __builtin_amdgcn_readfirstlane(meta[0]) : 0, cnt0 = h0 >= 0 ? h0 - lo0 + 1 : 0;
+  const int lo1 = h1 >= 0 ? __builtin_amdgcn_readfirstlane(meta[2]) : 0, cnt1 = h1 >= 0 ? h1 - lo1 + 1 : 0;
+  const int lo2 = h2 >= 0 ? __builtin_amdgcn_readfirstlane(meta[4]) : 0, cnt2 = h2 >= 0 ? h2 - lo2 + 1 : 0;
+  const bool win = !force_gather && cnt0 <= WMAX && cnt1 <= WMAX && cnt2 <= WMAX;
+  // window mode: one fill per (g, kc) serves its three stages; gather mode: one fill (the BM rows of
+  // the stage's tap) per stage.  Fill f goes to window buffer f & 1.
+#define UNIT_SEL(gt, v0, v1, v2) ((gt) == 0 ? (v0) : ((gt) == 1 ? (v1) : (v2)))
+#define WIN_FILL(f)                                                                                        \
+  do {                                                                                                     \
+    const int u_ = win ? (f) : (f) / 3, g_ = u_ / kchunks, kc_ = u_ - g_ * kchunks;                        \
+    const int tap_ = win ? 0 : 3 * g_ + ((f)-3 * u_);                                                      \
+    win_fill<BK, WMAX, BM, NWL, NWP, NPA>(smem + ((f)&1) * ABUF, rs_in, lw, lane, win,                     \
+                                          UNIT_SEL(g_, lo0, lo1, lo2), win ? UNIT_SEL(g_, cnt0, cnt1, cnt2) : BM, \
+                                          kc_, nbr_lds + tap_ * BM, in_row_bytes, LL);                     \
+  } while (0)
+  const int spf = win ? 3 : 1;                 // stages per fill
+  const int nfills = nstages / spf;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (loader) {
+    // ---- loader waves.  Per stage: the next fill (at the first stage of the current one) and the weights
+    // two stages ahead; vmcnt(NWP) = "all but the weight pieces issued last have landed".
+    WIN_FILL(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue only: stage 1's weights are waited too
+    __builtin_amdgcn_s_barrier();
+    int s = 0;
+    for (int f = 0; f < nfills; ++f) {
+      for (int t = 0; t < spf; ++t, ++s) {
+        if (a.diag != 2) {
+          if (t == 0 && f + 1 < nfills) WIN_FILL(f + 1);
+          if (s + 2 < nstages) WIN_WLOAD(s + 2);
+        }
+        if (s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GGW_STAMP(lw == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // loader 0 ready for the barrier
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  } else {
+    // ---- compute waves: LDS reads + MFMAs only
+    const int wm = wave / NWN, wn = wave % NWN;
+    int aoff[TM], akey[TM];   // window row (byte offset, swizzle key) of this lane's sites for the stage's tap
+#define ROW_TABLE(s_)                                                        \
+  do {                                                                       \
+    const int u_ = (s_) / 3, g_ = u_ / kchunks, tap_ = 3 * g_ + ((s_)-3 * u_); \
+    const int lo_ = UNIT_SEL(g_, lo0, lo1, lo2);                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                         \
+      const int site = wm * WTM + i * 32 + lr;                               \
+      const int src = nbr_lds[tap_ * BM + site];                             \
+      const int R = src >= 0 ? (win ? src - lo_ : site) : WMAX;              \
+      aoff[i] = R * ROWB;                                                    \
+      akey[i] = swz<BK>(R);                                                  \
+    }                                                                        \
+  } while (0)
+    ROW_TABLE(0);
+    GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 3);
+    __builtin_amdgcn_s_barrier();
+    GGW_STAMP(wave == 0, 1);
+    for (int s = 0; s < nstages; ++s) {
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
+      const char* abase = smem + ((win ? s / 3 : s) & 1) * ABUF;
+      const char* wbase = wsm + (s % 3) * WBUF;
+      if (a.diag != 1) {
+        // Hand-ordered k-steps (inline asm; hipcc's own order exposed the LDS latency once per k-step, ~500 of
+        // a stage's 1600 cycles, and sched_group_barrier made it chain MFMAs on one accumulator).  Fragments
+        // are double-buffered: the reads of step ks+1 go out two per MFMA behind the first MFMAs of step ks
+        // and are waited for (lgkmcnt counts only what this block issued) at the top of step ks+1.
+        const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)abase;
+        const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)wbase;
+        unsigned ra[TM], rw[TN];   // per-lane row base + swizzle key folded with lh
+        int ka[TM], kw[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ra[i] = a_lds + (unsigned)aoff[i]; ka[i] = akey[i] ^ lh; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row_ = wn * WTN + j * 32 + lr;
+          rw[j] = w_lds + (unsigned)(row_ * ROWB);
+          kw[j] = swz<BK>(row_) ^ lh;
+        }
+        bf16x8 fa[2][TM], fw[2][TN];
+#define DS_READ_FRAG(dst, base, key, ks) \
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((base) + (unsigned)(((2 * (ks)) ^ (key)) << 4)))
+#pragma unroll
+        for (int i = 0; i < TM; ++i) DS_READ_FRAG(fa[0][i], ra[i], ka[i], 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) DS_READ_FRAG(fw[0][j], rw[j], kw[j], 0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          int nxt = 0;   // next step's fragment reads issued so far (TM activations first, then TN weights)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+                           : "+v"(acc[i][j])
+                           : "v"(fw[ks & 1][j]), "v"(fa[ks & 1][i]));
+              if (ks + 1 < BK / 16) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r, ++nxt) {
+                  if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], ks + 1);
+                  else if (nxt < TM + TN) DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], ks + 1);
+                }
+              }
+            }
+        }
+        // the accumulators were written by opaque asm: cover the MFMA -> VALU read hazard by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      }
+      if (s + 1 < nstages) ROW_TABLE(s + 1);   // the rulebook tile is static: next stage's rows before the barrier
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
+    }
+  }
+  GGW_STAMP(wave == 0, 2);
+
+  // ---- epilogue.  D row = output channel (reg&3) + 8*(reg>>2) + 4*lh, D col = site lr.  The compute
+  // waves park scale*acc+shift as fp32 in the (now free) staging pool; then every wave writes whole
+  // output rows -- residual rows are read coalesced here, not 8 bytes per lane from 32 rows.
+  TOut* out = reinterpret_cast<TOut*>(a.out);
+  constexpr int EROW = BN * 4 + 16;                  // bytes per parked row (+16: rows of a wave on different banks)
+  static_assert((size_t)BM * EROW <= (size_t)POOL, "fp32 tile must fit the staging pool");
+  char* et = smem;
+  if (!loader) {
+    const int wm = wave / NWN, wn = wave % NWN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rl = wm * WTM + i * 32 + lr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = wn * WTN + j * 32 + 8 * g + 4 * lh;
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+          *reinterpret_cast<f32x4*>(et + rl * EROW + cl * 4) = v;   // raw: scale / shift are applied per lane below
+        }
+      }
+    }
+  }
+  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 4);
+  __syncthreads();
+  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 5);
+  // 16-B stores: 8 channels per lane for bf16 (a store instruction costs the same issue time whatever its width)
+  constexpr int CPL = sizeof(TOut) == 2 && BN % 8 == 0 ? 8 : 4;   // channels per lane
+  constexpr int LPR = BN / CPL;                    // lanes per output row
+  constexpr int RPI = 64 / LPR > 0 ? 64 / LPR : 1; // rows per wave-instruction
+  static_assert(LPR <= 64, "row wider than a wavefront");
+  const int sub = lane / LPR, cl = (lane % LPR) * CPL;
+  f32x4 sc[CPL / 4], sh[CPL / 4];   // this lane's channels are the same for every row it writes
+#pragma unroll
+  for (int h = 0; h < CPL / 4; ++h) {
+    sc[h] = *reinterpret_cast<const f32x4*>(sc_lds + cl + 4 * h);
+    sh[h] = *reinterpret_cast<const f32x4*>(sc_lds + BN + cl + 4 * h);
+  }
+  const bool wide = CPL == 8 && n0 + cl + 8 <= a.cout_total && (a.out_ld & 7) == 0 && (a.res_ld & 7) == 0 &&
+                    ((uintptr_t)a.out & 15) == 0 && ((uintptr_t)a.residual & 15) == 0;
+#pragma unroll 8
+  for (int r0 = wave * RPI; r0 < BM; r0 += NW * RPI) {
+    const int rl = r0 + sub, m = m0 + rl;
+    if (!(rl < BM && m < M)) continue;
+    const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
+#pragma unroll
+    for (int h = 0; h < CPL / 4; ++h) {
+      const int c = cl + 4 * h;
+      f32x4 v = *reinterpret_cast<const f32x4*>(et + rl * EROW + c * 4) * sc[h] + sh[h];
+      f32x4 v2 = v;
+      if constexpr (CPL == 8) {
+        if (wide) {   // both halves, one 16-B residual load and one 16-B store
+          if (h == 1) break;
+          v2 = *reinterpret_cast<const f32x4*>(et + rl * EROW + c * 4 + 16) * sc[CPL / 4 - 1] + sh[CPL / 4 - 1];
+          if (a.residual) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.residual + (size_t)m * a.res_ld + n0 + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += (float)rv[r]; v2[r] += (float)rv[4 + r]; }
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = fmaxf(v[r], 0.f); v2[r] = fmaxf(v2[r], 0.f); }
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { o[r] = (__bf16)v[r]; o[4 + r] = (__bf16)v2[r]; }
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + c) = o;
+          continue;
+        }
+      }
+      if (n0 + c >= a.cout_total) continue;
+      if (a.residual) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + n0 + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      OutOps<TOut>::store4(out + orow * a.out_ld + n0 + c, v);
+    }
+  }
+  GGW_STAMP(wave == 0, 3);
+#endif
+}
+
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut>
+static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
+  constexpr int NT = (NWM * NWN + NWL) * 64;
+  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX>() + (size_t)9 * BM * 4 + 32 + (size_t)BN * 8;
+  static_assert(LDS <= 160 * 1024, "window kernel LDS budget");
+  static const int force_gather = getenv("PN_GG_WIN_GATHER") != nullptr;
+  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut>;
+  static bool attr_set = false;
+  if (!attr_set && LDS > 32 * 1024) {
+    PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_set = true;
+  }
+  const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN), groups);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, stream, a, force_gather);
+  PN_CHECK_LAUNCH("gg_win_kernel");
+  return PN_OK;
+}
+
+template <typename TOut>
+static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
+  const int N = a.cout_total;
+  static const char* force = getenv("PN_GG_WIN_CFG");
+  const char f = force ? force[0] : 0;
+  if (a.cin % 64 != 0) {   // 32 input channels
+    if (N <= 32) return launch_win<256, 32, 4, 1, 2, 32, 352, TOut>(a, groups, stream);
+    return launch_win<256, 64, 4, 1, 4, 32, 352, TOut>(a, groups, stream);
+  }
+  if (N <= 32) return launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
+  if (N <= 64) {
+    if (f == 'H') return launch_win<128, 64, 2, 1, 2, 64, 192, TOut>(a, groups, stream);   // two workgroups per CU
+    return launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
+  }
+  if (N <= 128 || f == 'N') {
+    if (f == 'S') return launch_win<128, 128, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
+    return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
+  }
+  // 8 compute waves of 64 x 64 + 8 loaders: measured 2-6 % ahead of 4 x (64 x 128) + 4 on every 256-wide shape
+  if (f == 'D') return launch_win<128, 256, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
+  return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
+}
+
+int pn_gg_try_window(const GGArgs& a, int groups, bool out_fp32, hipStream_t stream) {
+  static const bool off = getenv("PN_GG_NO_WIN") != nullptr;
+  if (off || a.ntaps != 9 || a.nbr == nullptr || a.in_bytes == 0 || a.diag == 3) return -1;
+  return out_fp32 ? dispatch_win<float>(a, groups, stream) : dispatch_win<__bf16>(a, groups, stream);
+}
