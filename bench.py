@@ -122,10 +122,11 @@ def main():
         traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same shape)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f).get(f"spconv_{cin}x{cout}", {}).get("hbm_bytes_per_launch")
+                pmc = json.load(f)
+                traffic = (pmc.get(f"spconv_{cin}x{cout}_window") or pmc.get(f"spconv_{cin}x{cout}", {})).get("hbm_bytes_per_launch")
         except OSError:
             pass
-        roof = {"bound": "mfma", "kernel": f"gather_gemm_kernel<128,256,2,4,64,{args.dtype}> (sparse SubM {cin}->{cout})",
+        roof = {"bound": "mfma", "kernel": f"gg_win_kernel<128,256,2,4,8,64,192,{args.dtype}> (window-staged gather-GEMM, sparse SubM {cin}->{cout})",
                 "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "active_pairs": pairs, "rows": rows}

@@ -499,7 +499,8 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   }
   if (N <= 32) return launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (N <= 64) {
-    if (f == 'H') return launch_win<128, 64, 2, 1, 2, 64, 192, TOut>(a, groups, stream);   // two workgroups per CU
+    if (f == 'H') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut>(a, groups, stream);   // two workgroups per CU
+    if (f == 'I') return launch_win<128, 64, 4, 1, 4, 64, 160, TOut>(a, groups, stream);   // ... with 32 x 64 wave tiles
     return launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
   if (N <= 128 || f == 'N') {
@@ -508,6 +509,7 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   }
   // 8 compute waves of 64 x 64 + 8 loaders: measured 2-6 % ahead of 4 x (64 x 128) + 4 on every 256-wide shape
   if (f == 'D') return launch_win<128, 256, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
+  if (f == 'M') return launch_win<256, 128, 4, 2, 8, 64, 320, TOut>(a, groups, stream);
   return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
 }
 

@@ -15,7 +15,8 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob("gpurun_out/pmc_gg/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gather_gemm" not in r["Kernel_Name"] or "Li128ELi256E" not in r["Kernel_Name"] and "128, 256" not in r["Kernel_Name"]:
+        if not (("gather_gemm" in r["Kernel_Name"] or "gg_win" in r["Kernel_Name"]) and
+                ("Li128ELi256E" in r["Kernel_Name"] or "128, 256" in r["Kernel_Name"])):
             continue
         a = agg[r["Counter_Name"]]
         a[0] += 1
