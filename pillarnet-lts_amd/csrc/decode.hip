@@ -205,9 +205,48 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
   }
   __syncthreads();
   int n = s_cnt;
-  if (n > DEC_LIST) {  // > 4096 cells inside the single cut-off bin: report, keep what fits
-    if (tid == 0) atomicOr(&status[0], 1);
-    n = DEC_LIST;
+  if (n > DEC_LIST) {
+    // More cells inside the single cut-off bin than the list holds (maps full of equal scores): report it,
+    // and collect again by a fixed rule -- every key above the cut-off bin, then the cut-off bin's cells in
+    // ascending cell order until the list is full -- so that the result does not depend on which thread's
+    // atomicAdd came first.  Only this degenerate case pays for the ordered pass.
+    if (tid == 0) { atomicOr(&status[0], 1); s_cnt = 0; }
+    __syncthreads();
+    for (int cell = tid; cell < cells; cell += SEL_THREADS) {
+      const unsigned key = kk[cell];
+      if (!key) continue;
+      int bin = key > C.key_lo ? (int)((key - C.key_lo) >> C.key_shift) : 0;
+      if (bin >= DEC_BINS) bin = DEC_BINS - 1;
+      if (bin > cut) {   // fewer than pre_max of these by the definition of the cut-off bin
+        const int pos = atomicAdd(&s_cnt, 1);
+        list[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cell);
+      }
+    }
+    __syncthreads();
+    int filled = s_cnt;              // same value in every thread
+    for (int base = 0; base < cells && filled < DEC_LIST; base += SEL_THREADS) {
+      const int cell = base + tid;
+      const unsigned key = cell < cells ? kk[cell] : 0u;
+      int bin = key > C.key_lo ? (int)((key - C.key_lo) >> C.key_shift) : 0;
+      if (bin >= DEC_BINS) bin = DEC_BINS - 1;
+      const bool hit = key != 0u && bin == cut;
+      const unsigned long long m = __ballot(hit);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) sfx[wv] = __popcll(m);
+      __syncthreads();
+      int before = 0, total = 0;
+      for (int w = 0; w < SEL_THREADS / 64; ++w) {
+        const int c = sfx[w];
+        before += w < wv ? c : 0;
+        total += c;
+      }
+      const int pos = filled + before + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && pos < DEC_LIST)
+        list[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cell);
+      filled += total;
+      __syncthreads();
+    }
+    n = filled < DEC_LIST ? filled : DEC_LIST;
   }
   int p2 = 1;
   while (p2 < n) p2 <<= 1;

@@ -12,6 +12,8 @@ This module compiles eval-mode `Sequential`s into lists of fused launches ("plan
 and their state dicts are untouched (plans are rebuilt when a parameter changes).  bf16 only -- the
 fp32 parity path keeps running the torch modules.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -246,8 +248,11 @@ class PlanCache:
     def get(self, module, builder):
         v = params_version(module)
         hit = self._d.get(id(module))
-        if hit is None or hit[0] != v:
-            hit = (v, builder(module))
+        # id() values are recycled once a module is collected: the entry must belong to THIS module
+        if hit is None or hit[0] != v or hit[2]() is not module:
+            if len(self._d) > 256:
+                self._d = {k: e for k, e in self._d.items() if e[2]() is not None}
+            hit = (v, builder(module), weakref.ref(module))
             self._d[id(module)] = hit
         return hit[1]
 

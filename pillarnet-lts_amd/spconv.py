@@ -68,7 +68,8 @@ class SparseConvTensor:
     # -- spconv API ---------------------------------------------------------------------------
     @property
     def capacity(self):
-        return self.features_cap.shape[0]
+        # (index-only tensors -- features None -- exist while the rulebooks are prefetched)
+        return (self.features_cap if self.features_cap is not None else self.indices_cap).shape[0]
 
     def num_active_host(self):
         if self._n_host is None:
