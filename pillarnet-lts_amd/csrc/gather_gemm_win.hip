@@ -106,15 +106,18 @@ extern "C" int pn_gg_win_debug_stamps(unsigned long long* host_out, int n) {
 }
 
 // LDS pool = the staging buffers (2 windows + 3 weight tiles), or the parked fp32 output tile if larger
-template <int BM, int BN, int BK, int WMAX>
+template <int BM, int BN, int BK, int WMAX, bool UNIT>
 constexpr int win_pool_bytes() {
   constexpr int RPP = 1024 / (BK * 2);
-  constexpr int staging = 2 * (WMAX + RPP) * BK * 2 + 3 * BN * BK * 2;
+  constexpr int staging = 2 * (WMAX + RPP) * BK * 2 + (UNIT ? 6 : 3) * BN * BK * 2;
   constexpr int parked = BM * (BN * 4 + 16);
   return staging > parked ? staging : parked;
 }
 
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut>
+// UNIT (narrow layers, where a tap's weight tile is small): in window mode a stage is a whole kernel row --
+// its three taps' weights land together, double-buffered -- so a tile has 3*kchunks barriers instead of
+// 9*kchunks; a 16-MFMA stage spent more time on its barrier and first LDS reads than on its MFMAs.
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT>
 __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a, int force_gather) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no __amdgpu_buffer_rsrc_t to check the helpers against
   constexpr int NWC = NWM * NWN;              // compute waves; waves NWC .. NWC+NWL-1 are loaders
@@ -126,7 +129,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int ABUF = (WMAX + RPP) * ROWB;   // window + one piece of zero rows (row WMAX = "no neighbour")
   constexpr int WBUF = BN * ROWB;
-  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX>();   // staging buffers; the epilogue parks the fp32 tile here
+  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX, UNIT>();   // staging buffers; the epilogue parks the fp32 tile here
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
   static_assert(NWM * NWN + NWL >= 3, "three waves reduce the rulebook tile");
   static_assert(WMAX % RPP == 0 && BM % RPP == 0 && BN % RPP == 0 && BM <= WMAX, "window geometry");
@@ -186,12 +189,13 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       LL.a[j] = (unsigned)r * in_row_bytes + (unsigned)((slot ^ swz<BK>(r)) << 4);
     }
   }
-#define WIN_WLOAD(s_)                                                                                     \
+#define WIN_WLOAD_SLOT(s_, slot_)                                                                         \
   do {                                                                                                    \
     const int u_ = (s_) / 3, g_ = u_ / kchunks;                                                           \
-    win_wload<BK, BN, NWL, NWP, NPA>(wsm + ((s_) % 3) * WBUF, rs_wt, lw, 3 * g_ + ((s_)-3 * u_),           \
+    win_wload<BK, BN, NWL, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, 3 * g_ + ((s_)-3 * u_),              \
                                      u_ - g_ * kchunks, a.cout_total, a.cin, LL);                         \
   } while (0)
+#define WIN_WLOAD(s_) WIN_WLOAD_SLOT(s_, (s_) % 3)
 
   // the weights do not depend on the rulebook: stages 0 and 1 are under way before anything else
   if (loader) {
@@ -282,30 +286,48 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool unit_mode = UNIT && win;
   if (loader) {
-    // ---- loader waves.  Per stage: the next fill (at the first stage of the current one) and the weights
-    // two stages ahead; vmcnt(NWP) = "all but the weight pieces issued last have landed".
     WIN_FILL(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue only: stage 1's weights are waited too
-    __builtin_amdgcn_s_barrier();
-    int s = 0;
-    for (int f = 0; f < nfills; ++f) {
-      for (int t = 0; t < spf; ++t, ++s) {
-        if (a.diag != 2) {
-          if (t == 0 && f + 1 < nfills) WIN_FILL(f + 1);
-          if (s + 2 < nstages) WIN_WLOAD(s + 2);
+    if (unit_mode) {
+      // ---- loader waves, unit stages: everything of unit u+1 (window + three weight tiles) goes out during
+      // unit u and is waited for at its end; a unit is long enough (48+ MFMAs per wave) to cover the round trip
+      WIN_WLOAD_SLOT(2, 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int u = 0; u < nfills; ++u) {
+        if (u + 1 < nfills && a.diag != 2) {
+          WIN_FILL(u + 1);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) WIN_WLOAD_SLOT(3 * (u + 1) + t, ((u + 1) & 1) * 3 + t);
         }
-        if (s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GGW_STAMP(lw == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // loader 0 ready for the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      // ---- loader waves.  Per stage: the next fill (at the first stage of the current one) and the weights
+      // two stages ahead; vmcnt(NWP) = "all but the weight pieces issued last have landed".
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue only: stage 1's weights are waited too
+      __builtin_amdgcn_s_barrier();
+      int s = 0;
+      for (int f = 0; f < nfills; ++f) {
+        for (int t = 0; t < spf; ++t, ++s) {
+          if (a.diag != 2) {
+            if (t == 0 && f + 1 < nfills) WIN_FILL(f + 1);
+            if (s + 2 < nstages) WIN_WLOAD(s + 2);
+          }
+          if (s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          GGW_STAMP(lw == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // loader 0 ready for the barrier
+          __builtin_amdgcn_s_barrier();
+        }
       }
     }
   } else {
     // ---- compute waves: LDS reads + MFMAs only
     const int wm = wave / NWN, wn = wave % NWN;
-    int aoff[TM], akey[TM];   // window row (byte offset, swizzle key) of this lane's sites for the stage's tap
-#define ROW_TABLE(s_)                                                        \
+    int aoff[3][TM], akey[3][TM];   // window row (byte offset, swizzle key) of this lane's sites, per tap slot
+#define ROW_TABLE(s_, slot_)                                                 \
   do {                                                                       \
     const int u_ = (s_) / 3, g_ = u_ / kchunks, tap_ = 3 * g_ + ((s_)-3 * u_); \
     const int lo_ = UNIT_SEL(g_, lo0, lo1, lo2);                             \
@@ -313,70 +335,92 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       const int site = wm * WTM + i * 32 + lr;                               \
       const int src = nbr_lds[tap_ * BM + site];                             \
       const int R = src >= 0 ? (win ? src - lo_ : site) : WMAX;              \
-      aoff[i] = R * ROWB;                                                    \
-      akey[i] = swz<BK>(R);                                                  \
+      aoff[slot_][i] = R * ROWB;                                             \
+      akey[slot_][i] = swz<BK>(R);                                           \
     }                                                                        \
   } while (0)
-    ROW_TABLE(0);
-    GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 3);
-    __builtin_amdgcn_s_barrier();
-    GGW_STAMP(wave == 0, 1);
-    for (int s = 0; s < nstages; ++s) {
-      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
-      const char* abase = smem + ((win ? s / 3 : s) & 1) * ABUF;
-      const char* wbase = wsm + (s % 3) * WBUF;
-      if (a.diag != 1) {
-        // Hand-ordered k-steps (inline asm; hipcc's own order exposed the LDS latency once per k-step, ~500 of
-        // a stage's 1600 cycles, and sched_group_barrier made it chain MFMAs on one accumulator).  Fragments
-        // are double-buffered: the reads of step ks+1 go out two per MFMA behind the first MFMAs of step ks
-        // and are waited for (lgkmcnt counts only what this block issued) at the top of step ks+1.
-        const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)abase;
-        const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)wbase;
-        unsigned ra[TM], rw[TN];   // per-lane row base + swizzle key folded with lh
-        int ka[TM], kw[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) { ra[i] = a_lds + (unsigned)aoff[i]; ka[i] = akey[i] ^ lh; }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row_ = wn * WTN + j * 32 + lr;
-          rw[j] = w_lds + (unsigned)(row_ * ROWB);
-          kw[j] = swz<BK>(row_) ^ lh;
-        }
-        bf16x8 fa[2][TM], fw[2][TN];
 #define DS_READ_FRAG(dst, base, key, ks) \
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((base) + (unsigned)(((2 * (ks)) ^ (key)) << 4)))
+    // Hand-ordered k-steps of one (tap, channel chunk) (inline asm; hipcc's own order exposed the LDS latency
+    // once per k-step, ~500 of a stage's 1600 cycles, and sched_group_barrier made it chain MFMAs on one
+    // accumulator).  Fragments are double-buffered: the reads of step ks+1 go out two per MFMA behind the
+    // first MFMAs of step ks and are waited for (lgkmcnt counts only what this block issued) at the top of
+    // step ks+1.
+#define STAGE_MFMA(abase_, wbase_, slot_)                                                                  \
+  do {                                                                                                     \
+    const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(abase_);      \
+    const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(wbase_);      \
+    unsigned ra[TM], rw[TN];                                                                               \
+    int ka[TM], kw[TN];                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
+      ra[i] = a_lds + (unsigned)aoff[slot_][i];                                                            \
+      ka[i] = akey[slot_][i] ^ lh;                                                                         \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                       \
+      const int row_ = wn * WTN + j * 32 + lr;                                                             \
+      rw[j] = w_lds + (unsigned)(row_ * ROWB);                                                             \
+      kw[j] = swz<BK>(row_) ^ lh;                                                                          \
+    }                                                                                                      \
+    bf16x8 fa[2][TM], fw[2][TN];                                                                           \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) DS_READ_FRAG(fa[0][i], ra[i], ka[i], 0);                \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) DS_READ_FRAG(fw[0][j], rw[j], kw[j], 0);                \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                               \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+      int nxt = 0;                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {      \
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                                             \
+                     : "+v"(acc[i][j])                                                                     \
+                     : "v"(fw[ks & 1][j]), "v"(fa[ks & 1][i]));                                            \
+        if (ks + 1 < BK / 16) {                                                                            \
+          _Pragma("unroll") for (int r = 0; r < 2; ++r, ++nxt) {                                           \
+            if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], ks + 1);                   \
+            else if (nxt < TM + TN)                                                                        \
+              DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], ks + 1);                \
+          }                                                                                                \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+  } while (0)
+    if (unit_mode) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) DS_READ_FRAG(fa[0][i], ra[i], ka[i], 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) DS_READ_FRAG(fw[0][j], rw[j], kw[j], 0);
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          int nxt = 0;   // next step's fragment reads issued so far (TM activations first, then TN weights)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
-                           : "+v"(acc[i][j])
-                           : "v"(fw[ks & 1][j]), "v"(fa[ks & 1][i]));
-              if (ks + 1 < BK / 16) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r, ++nxt) {
-                  if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], ks + 1);
-                  else if (nxt < TM + TN) DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], ks + 1);
-                }
-              }
-            }
-        }
-        // the accumulators were written by opaque asm: cover the MFMA -> VALU read hazard by hand
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-      }
-      if (s + 1 < nstages) ROW_TABLE(s + 1);   // the rulebook tile is static: next stage's rows before the barrier
-      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int t = 0; t < 3; ++t) ROW_TABLE(t, t);
       __builtin_amdgcn_s_barrier();
-      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
+      GGW_STAMP(wave == 0, 1);
+      for (int u = 0; u < nfills; ++u) {
+        GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 0);
+        const char* abase = smem + (u & 1) * ABUF;
+        if (a.diag != 1) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) STAGE_MFMA(abase, wsm + ((u & 1) * 3 + t) * WBUF, t);
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // opaque-asm MFMA -> VALU read hazard
+        }
+        if (u + 1 < nfills) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) ROW_TABLE(3 * (u + 1) + t, t);   // static rulebook tile: before the barrier
+        }
+        GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 2);
+      }
+    } else {
+      ROW_TABLE(0, 0);
+      GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 3);
+      __builtin_amdgcn_s_barrier();
+      GGW_STAMP(wave == 0, 1);
+      for (int s = 0; s < nstages; ++s) {
+        GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
+        const char* abase = smem + ((win ? s / 3 : s) & 1) * ABUF;
+        if (a.diag != 1) {
+          STAGE_MFMA(abase, wsm + (s % 3) * WBUF, 0);
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // opaque-asm MFMA -> VALU read hazard
+        }
+        if (s + 1 < nstages) ROW_TABLE(s + 1, 0);   // static rulebook tile: next stage's rows before the barrier
+        GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
+      }
     }
   }
   GGW_STAMP(wave == 0, 2);
@@ -470,13 +514,13 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #endif
 }
 
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut>
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT = false>
 static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = (NWM * NWN + NWL) * 64;
-  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX>() + (size_t)9 * BM * 4 + 32 + (size_t)BN * 8;
+  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT>() + (size_t)9 * BM * 4 + 32 + (size_t)BN * 8;
   static_assert(LDS <= 160 * 1024, "window kernel LDS budget");
   static const int force_gather = getenv("PN_GG_WIN_GATHER") != nullptr;
-  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut>;
+  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT>;
   static bool attr_set = false;
   if (!attr_set && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
@@ -493,18 +537,25 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   const int N = a.cout_total;
   static const char* force = getenv("PN_GG_WIN_CFG");
   const char f = force ? force[0] : 0;
+  const bool unit = f != 'P';   // 'P': per-tap stages everywhere (tuning aid)
   if (a.cin % 64 != 0) {   // 32 input channels
-    if (N <= 32) return launch_win<256, 32, 4, 1, 2, 32, 352, TOut>(a, groups, stream);
-    return launch_win<256, 64, 4, 1, 4, 32, 352, TOut>(a, groups, stream);
+    if (N <= 32) return unit ? launch_win<256, 32, 4, 1, 2, 32, 352, TOut, true>(a, groups, stream)
+                             : launch_win<256, 32, 4, 1, 2, 32, 352, TOut>(a, groups, stream);
+    return unit ? launch_win<256, 64, 4, 1, 4, 32, 352, TOut, true>(a, groups, stream)
+                : launch_win<256, 64, 4, 1, 4, 32, 352, TOut>(a, groups, stream);
   }
-  if (N <= 32) return launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
+  if (N <= 32) return unit ? launch_win<256, 32, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
+                           : launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (N <= 64) {
     if (f == 'H') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut>(a, groups, stream);   // two workgroups per CU
     if (f == 'I') return launch_win<128, 64, 4, 1, 4, 64, 160, TOut>(a, groups, stream);   // ... with 32 x 64 wave tiles
-    return launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
+    return unit ? launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
+                : launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
   if (N <= 128 || f == 'N') {
     if (f == 'S') return launch_win<128, 128, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
+    if (f == 'M') return launch_win<256, 128, 4, 2, 8, 64, 320, TOut>(a, groups, stream);
+    if (f == 'U') return launch_win<128, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);   // unit stages
     return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
   // 8 compute waves of 64 x 64 + 8 loaders: measured 2-6 % ahead of 4 x (64 x 128) + 4 on every 256-wide shape
