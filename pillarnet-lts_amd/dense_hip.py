@@ -260,6 +260,10 @@ class PlanCache:
 PLANS = PlanCache()
 
 
+import os
+_HEAD_DIRECT = bool(os.environ.get("PN_HEAD_DIRECT"))   # tuning switch, see HeadPlan.run
+
+
 # ---- CenterHead: shared conv, all first-layer towers as ONE conv, one small conv per task ----------
 _ORDER = ("reg", "height", "dim", "rot", "vel", "iou", "hm")
 
@@ -335,6 +339,20 @@ class HeadPlan:
             dev = x.t.device
             tow = torch.empty((rows, cols), dtype=torch.bfloat16, device=dev)
             _launch(x.t, cin, nbr, 9, rows, w, scale, shift, True, tow, cols, in_ld=x.ld)
+            if fused is not None and _HEAD_DIRECT:
+                # all tasks' 3x3 output convs as ONE grouped launch of the window kernel (unit stages, fp32 out)
+                kin, npad, wz, ones, zeros, bias, k0 = fused
+                G = len(task_convs)
+                w9 = torch.stack([tc[5] for tc in task_convs]).contiguous()        # [G, 9, npad, kin]
+                one = ones[:G * npad].contiguous()
+                maps = torch.empty((G, rows, npad), dtype=torch.float32, device=dev)
+                rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, _lib.ptr(nbr), nbr.shape[1], 9,
+                                              rows, _lib.ptr(w9), npad, G, _lib.ptr(one), _lib.ptr(bias), 0,
+                                              _lib.ptr(maps), npad, rows * npad, 1, _lib.current_stream(dev))
+                _lib.check(rc, "pn_gather_gemm_grouped")
+                for g, (t, _k0, _kin, nout, _npad, _wt, _ones, _bias) in enumerate(task_convs):
+                    out[t] = (maps[g], nout, npad, x.B, Ho, Wo)
+                continue
             if fused is not None:
                 kin, npad, wz, ones, zeros, bias, k0 = fused
                 G = len(task_convs)
