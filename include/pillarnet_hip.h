@@ -308,6 +308,23 @@ int pn_roi_grid_pool(int dtype, const float* rois, int roi_dim, int batch, int r
                      int grid, const void* map, int map_ld, int H, int W, int C, float x_min,
                      float y_min, float cell_size, float* out, float* points, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * Multi-sweep merge (the data step in front of the reader).
+ * Replaces the nuScenes branch of LoadPointCloudFromFile.__call__ with read_sweep / remove_close
+ * (det3d/datasets/pipelines/loading.py:38-61,103-140) for sweeps already resident in HBM:
+ *   raw [n_total, raw_dim] fp32 = the .bin files back to back (key sweep first); sweep s owns rows
+ *   [sweep_start[s], sweep_start[s+1]) (HOST array of n_sweeps+1 ints).  Per sweep (device arrays):
+ *   transform[s][16] float64 row-major 4x4 (used where has_transform[s]), time_lag[s] fp32,
+ *   filter_close[s] (1: drop points with |x| < radius and |y| < radius, tested before the transform).
+ * out [<= n_total, use_dim + 1] fp32: (x', y', z', raw[3..use_dim), time lag), reference row order
+ * (a stable compaction); out_count: device int32.  Workspace: pn_merge_sweeps_workspace_bytes(n_total).
+ * ------------------------------------------------------------------------ */
+size_t pn_merge_sweeps_workspace_bytes(int n_points);
+int pn_merge_sweeps(const float* raw, int raw_dim, int use_dim, const int32_t* sweep_start_host,
+                    int n_sweeps, const double* transform, const uint8_t* has_transform,
+                    const float* time_lag, const uint8_t* filter_close, float radius, float* out,
+                    int32_t* out_count, void* workspace, size_t workspace_bytes, pnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

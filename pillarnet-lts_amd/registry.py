@@ -60,3 +60,4 @@ DETECTORS = Registry("detector")
 SECOND_STAGE = Registry("second_stage")
 ROI_HEAD = Registry("roi_head")
 POINT_HEAD = Registry("point_head")
+PIPELINES = Registry("pipeline")     # det3d/datasets/registry.py:4

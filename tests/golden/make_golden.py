@@ -13,6 +13,7 @@ Reference code executed here (imported from /root/reference, nothing copied):
   det3d/ops/iou3d_nms/src/iou3d_cpu.cpp (compiled, oracle/_ref)      -> iou3d.npz
   det3d.models.second_stage.BEVStrideFeature, roi_heads.RoIMIXHead, point_heads.PointHead,
   detectors.pillar_rcnn.PillarRCNN.post_process       -> rcnn.npz
+  det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz
 
 The reference imports packages this image lacks (numba, addict, spconv, torchvision, terminaltables,
 its own un-built CUDA extensions); they are replaced by inert in-process module objects so that the
@@ -469,6 +470,53 @@ def golden_rcnn():
     save("rcnn.npz", **arrays)
 
 
+def golden_loading():
+    """LoadPointCloudFromFile (nuScenes branch) / read_sweep of the reference on .bin sweeps written to a
+    temporary directory from seeded arrays; the fixture keeps the arrays, the transforms, the order the
+    reference's np.random.choice picked and the `combined` cloud it produced."""
+    import tempfile
+    # import ONLY loading.py: the dataset packages' __init__ files pull nuscenes-devkit / waymo TF
+    for pkg in ("det3d.datasets", "det3d.datasets.pipelines"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules.setdefault(pkg, m)
+    from det3d.datasets.pipelines.loading import LoadPointCloudFromFile
+    rs = np.random.RandomState(21)
+    n_sw, arrays = 4, {}
+    with tempfile.TemporaryDirectory() as d:
+        raws, sweeps = [], []
+        for i in range(n_sw):
+            n = int(rs.randint(1500, 2500))
+            raw = np.concatenate([rs.randn(n, 3) * [12.0, 12.0, 1.5], rs.rand(n, 1) * 255, rs.randint(0, 32, (n, 1))],
+                                 axis=1).astype(np.float32)
+            raw[: n // 10, :2] = rs.uniform(-1.3, 1.3, (n // 10, 2))          # a cluster around the ego vehicle
+            raw[5, :2], raw[6, :2], raw[7, :2] = (1.0, 0.2), (0.999999, -0.5), (-0.3, -1.0)   # on / at the 1 m edge
+            path = os.path.join(d, f"sweep{i}.bin")
+            raw.tofile(path)
+            raws.append(raw)
+            if i:
+                ang = rs.uniform(-0.2, 0.2)
+                T = np.eye(4)
+                T[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+                T[:3, 3] = rs.randn(3) * [2.0, 0.5, 0.05]
+                sweeps.append({"lidar_path": path, "transform_matrix": T if i != 2 else None,
+                               "time_lag": float(0.05 * i + rs.rand() * 1e-3)})
+        info = {"lidar_path": os.path.join(d, "sweep0.bin"), "sweeps": sweeps}
+        np.random.seed(33)
+        order = np.random.choice(len(sweeps), n_sw - 1, replace=False)
+        np.random.seed(33)
+        res, _ = LoadPointCloudFromFile(dataset="NuScenesDataset")(
+            {"lidar": {"nsweeps": n_sw}, "virtual": False}, info)
+    arrays["order"] = order
+    arrays["combined"] = res["lidar"]["combined"]
+    for i, raw in enumerate(raws):
+        arrays[f"raw.{i}"] = raw
+    for i, sw in enumerate(sweeps):
+        arrays[f"transform.{i}"] = np.full((4, 4), np.nan) if sw["transform_matrix"] is None else sw["transform_matrix"]
+        arrays[f"time_lag.{i}"] = np.asarray(sw["time_lag"])
+    save("loading.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is required"
     install_stubs()
@@ -479,3 +527,4 @@ if __name__ == "__main__":
     golden_decode(head, preds)
     golden_train(head)
     golden_rcnn()
+    golden_loading()

@@ -171,3 +171,18 @@ def test_rcnn_second_stage_restatement_matches_reference():
         np.testing.assert_array_equal(d["box3d_lidar"], g[f"det.{i}.box3d_lidar"])
         np.testing.assert_allclose(d["scores"], g[f"det.{i}.scores"], atol=1e-6)
     assert len(dets[1]["scores"]) == R - 3       # the padded proposals are dropped
+
+
+def test_loading_restatement_matches_reference():
+    """oracle/loading_oracle.py vs the reference's LoadPointCloudFromFile on the same sweeps (bit-exact: same
+    numpy expressions)."""
+    from oracle import loading_oracle as lo
+    g = load("loading.npz")
+    order = [int(i) for i in g["order"]]
+    raws = [g["raw.0"]] + [g[f"raw.{i + 1}"] for i in order]
+    mats = [None] + [None if np.isnan(g[f"transform.{i}"]).all() else g[f"transform.{i}"] for i in order]
+    lags = [0.0] + [float(g[f"time_lag.{i}"]) for i in order]
+    got = lo.combined(raws, mats, lags)
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, g["combined"])
+    assert got.shape[0] < sum(r.shape[0] for r in raws)      # the close-point filter removed something
