@@ -309,6 +309,16 @@ int pn_roi_grid_pool(int dtype, const float* rois, int roi_dim, int batch, int r
                      float y_min, float cell_size, float* out, float* points, pnStream stream);
 
 /* ------------------------------------------------------------------------
+ * points_in_boxes_2d_gpu of the reference's roiaware_pool3d extension (the PointHead target assigner of
+ * Pillar R-CNN): det3d/ops/roiaware_pool3d/src/roiaware_pool3d.cpp (points_in_boxes_2d_gpu),
+ * roiaware_pool3d_kernel.cu:39-50,354-377.  boxes [batch, boxes_num, 7] fp32 in pcdet convention
+ * (x, y, z, dx, dy, dz, heading), pts [batch, pts_num, 2]; box_idx_of_points [batch, pts_num] int32 =
+ * index of the first box whose BEV rectangle (margin 1e-5) holds the point, else -1 (always written).
+ * ------------------------------------------------------------------------ */
+int pn_points_in_boxes_2d(const float* boxes, const float* pts, int batch, int boxes_num, int pts_num,
+                          int32_t* box_idx_of_points, pnStream stream);
+
+/* ------------------------------------------------------------------------
  * Multi-sweep merge (the data step in front of the reader).
  * Replaces the nuScenes branch of LoadPointCloudFromFile.__call__ with read_sweep / remove_close
  * (det3d/datasets/pipelines/loading.py:38-61,103-140) for sweeps already resident in HBM:

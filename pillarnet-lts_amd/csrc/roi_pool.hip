@@ -76,3 +76,41 @@ extern "C" int pn_roi_grid_pool(int dtype, const float* rois, int roi_dim, int b
   PN_CHECK_LAUNCH("roi_grid_pool_batched_kernel");
   return PN_OK;
 }
+
+// ---- points_in_boxes_2d (det3d/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:16-21,39-50,354-377) ----
+// boxes [B, T, 7] in pcdet convention (x, y, z, dx, dy, dz, heading), pts [B, M, 2]; out [B, M] = index of the
+// FIRST box whose BEV rectangle (+1e-5 margin) holds the point, else -1.
+__global__ __launch_bounds__(256) void points_in_boxes_2d_kernel(int boxes_num, int pts_num,
+                                                                 const float* __restrict__ boxes,
+                                                                 const float* __restrict__ pts,
+                                                                 int32_t* __restrict__ out) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= pts_num) return;
+  const float* bx = boxes + (size_t)b * boxes_num * 7;
+  const float x = pts[((size_t)b * pts_num + p) * 2], y = pts[((size_t)b * pts_num + p) * 2 + 1];
+  int hit = -1;
+  for (int k = 0; k < boxes_num; ++k) {
+    const float* q = bx + k * 7;
+    const float sx = x - q[0], sy = y - q[1];
+    const float cosa = cosf(-q[6]), sina = sinf(-q[6]);
+    const float lx = sx * cosa + sy * (-sina), ly = sx * sina + sy * cosa;
+    // the CUDA source compares against double expressions (dx / 2.0 + MARGIN with float MARGIN)
+    if (fabs((double)lx) < (double)q[3] / 2.0 + (double)1e-5f && fabs((double)ly) < (double)q[4] / 2.0 + (double)1e-5f) {
+      hit = k;
+      break;
+    }
+  }
+  out[(size_t)b * pts_num + p] = hit;
+}
+
+extern "C" int pn_points_in_boxes_2d(const float* boxes, const float* pts, int batch, int boxes_num, int pts_num,
+                                     int32_t* box_idx_of_points, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (batch == 0 || pts_num == 0) return PN_OK;
+  PN_CHECK_ARG(pts && box_idx_of_points && batch > 0 && boxes_num >= 0 && (boxes || boxes_num == 0),
+               "pn_points_in_boxes_2d: null argument");
+  hipLaunchKernelGGL(points_in_boxes_2d_kernel, dim3(pn_div_up(pts_num, 256), batch), dim3(256), 0, stream, boxes_num,
+                     pts_num, boxes, pts, box_idx_of_points);
+  PN_CHECK_LAUNCH("points_in_boxes_2d_kernel");
+  return PN_OK;
+}

@@ -5,13 +5,17 @@ det3d/models/point_heads/point_head_simple.py, det3d/models/detectors/pillar_rcn
 
 Module trees / parameter names are the reference's.  The RoI pillar pooling (7x7 rotated grid +
 bilinear interpolation) is one HIP launch (`pn_roi_grid_pool`); the small 1-D conv MLPs of the RoI
-head stay torch ops.  Training of the second stage (ProposalTargetLayer, RoI / point losses) is not
-built: `forward(return_loss=True)` raises."""
+head stay torch ops.  Training: ProposalTargetLayer (HIP rotated 3-D IoU, the reference's RNG calls),
+RoI class / box losses, the PointHead's grid-point targets (`pn_points_in_boxes_2d`) and focal loss, and
+`combine_loss`; the pooled features are differentiable through a torch expression of the same bilinear
+weights (`roi_grid_pool` itself is forward-only)."""
 import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, builder, dense_hip
+import torch.nn.functional as Fn
+
+from . import _lib, builder, dense_hip, iou3d_nms
 from .detectors import BaseDetector
 from .nn_utils import build_norm_layer
 from .registry import DETECTORS, POINT_HEAD, ROI_HEAD, SECOND_STAGE
@@ -48,6 +52,39 @@ def roi_grid_pool(rois, feature_map, grid, cell_size, x_min, y_min, want_points=
         raise _lib.PillarnetHipError("roi_grid_pool: tensors must live on the GPU (no CPU fallback)")
     r = dense_hip.Rows.from_nchw(feature_map)
     return roi_grid_pool_rows(rois, r.t, r.B, r.H, r.W, grid, cell_size, x_min, y_min, want_points)
+
+
+def roi_grid_pool_torch(rois, feature_map, grid, cell_size, x_min, y_min):
+    """The same pooling as a differentiable torch expression (training: gradients reach the fused map through
+    the gathers): center_to_grid_box2d + rotation_2d (box_torch_ops.py:220-251) and bilinear_interpolate_torch
+    (center_utils.py:91-120), batched over samples."""
+    B, R = rois.shape[:2]
+    C, H, W = feature_map.shape[1:]
+    dev = rois.device
+    ii, jj = torch.meshgrid(torch.arange(grid, device=dev), torch.arange(grid, device=dev), indexing="ij")
+    idx = torch.stack([ii.reshape(-1), jj.reshape(-1)], -1).float()                     # (i, j)
+    flat = rois.reshape(B * R, -1).float()
+    dims = flat[:, None, 3:5]
+    local = (idx[None] + 0.5) / grid * dims - dims / 2
+    c, s = torch.cos(flat[:, 6]), torch.sin(flat[:, 6])
+    px = local[..., 0] * c[:, None] + local[..., 1] * s[:, None] + flat[:, None, 0]
+    py = -local[..., 0] * s[:, None] + local[..., 1] * c[:, None] + flat[:, None, 1]
+    pts = torch.stack([px, py], -1).view(B, R, grid * grid, 2)
+    x = ((px - x_min) / cell_size).view(B, -1)
+    y = ((py - y_min) / cell_size).view(B, -1)
+    x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
+    y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
+    rows = feature_map.permute(0, 2, 3, 1).reshape(B, H * W, C).float()
+    take = lambda yy, xx: torch.gather(rows, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
+    wa = (x1.float() - x) * (y1.float() - y)
+    wb = (x1.float() - x) * (y - y0.float())
+    wc = (x - x0.float()) * (y1.float() - y)
+    wd = (x - x0.float()) * (y - y0.float())
+    out = take(y0, x0) * wa.unsqueeze(-1) + take(y1, x0) * wb.unsqueeze(-1) + take(y0, x1) * wc.unsqueeze(-1) \
+        + take(y1, x1) * wd.unsqueeze(-1)
+    return out.view(B, R, grid * grid, C), pts
 
 
 class FoldedMLP:
@@ -158,10 +195,15 @@ class BEVStrideFeature(nn.Module):
 
     def forward(self, example):
         B, R = example["rois"].shape[:2]
-        r = dense_hip.Rows.from_nchw(self.fused_map(example))
-        pooled, pts = roi_grid_pool_rows(example["rois"], r.t, r.B, r.H, r.W, self.grid_size,
-                                         self.out_stride * self.pillar_size, self.point_cloud_range[0],
-                                         self.point_cloud_range[1])
+        fmap = self.fused_map(example)
+        if fmap.requires_grad:      # training: differentiable torch expression of the same pooling
+            pooled, pts = roi_grid_pool_torch(example["rois"], fmap, self.grid_size, self.out_stride * self.pillar_size,
+                                              self.point_cloud_range[0], self.point_cloud_range[1])
+        else:
+            r = dense_hip.Rows.from_nchw(fmap)
+            pooled, pts = roi_grid_pool_rows(example["rois"], r.t, r.B, r.H, r.W, self.grid_size,
+                                             self.out_stride * self.pillar_size, self.point_cloud_range[0],
+                                             self.point_cloud_range[1])
         example["roi_features"] = pooled.view(B, R, -1)
         example["point_features"] = pooled
         example["point_coords"] = pts
@@ -174,6 +216,146 @@ def rotate_points_along_z(points, angle):
     z, o = angle.new_zeros(points.shape[0]), angle.new_ones(points.shape[0])
     rot = torch.stack((c, -s, z, s, c, z, z, z, o), dim=1).view(-1, 3, 3).float()
     return torch.cat((torch.matmul(points[:, :, 0:3], rot), points[:, :, 3:]), dim=-1)
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    """roi_head_template.py:9-10."""
+    return val - torch.floor(val / period + offset) * period
+
+
+def points_in_boxes_2d(points, boxes):
+    """roiaware_pool3d_utils.py:58-81: points [B, M, 2], boxes [B, T, 7] (det3d convention) -> [B, M] int32,
+    index of the first box holding the point in the BEV plane, else -1.  One HIP launch."""
+    if points.device.type != "cuda":
+        raise _lib.PillarnetHipError("points_in_boxes_2d: tensors must live on the GPU (no CPU fallback)")
+    assert boxes.shape[0] == points.shape[0] and boxes.shape[2] == 7 and points.shape[2] == 2
+    B, M, _ = points.shape
+    bx = iou3d_nms.to_pcdet(boxes.reshape(-1, 7)).reshape(boxes.shape).contiguous().float()
+    pts = points.contiguous().float()
+    out = torch.empty((B, M), dtype=torch.int32, device=points.device)
+    rc = _lib.lib().pn_points_in_boxes_2d(_lib.ptr(bx), _lib.ptr(pts), B, boxes.shape[1], M, _lib.ptr(out),
+                                          _lib.current_stream(points.device))
+    _lib.check(rc, "pn_points_in_boxes_2d")
+    return out
+
+
+class ProposalTargetLayer(nn.Module):
+    """roi_heads/target_assigner/proposal_target_layer.py:8-232.  The sampling draws the reference's random
+    numbers in the reference's order (np.random.permutation / np.random.rand for foreground, CPU torch.randint
+    for background), so equal seeds give equal samples.  `iou_fn` defaults to the HIP rotated 3-D IoU."""
+
+    def __init__(self, roi_sampler_cfg, iou_fn=None):
+        super().__init__()
+        self.cfg = roi_sampler_cfg
+        self.iou_fn = iou_fn or iou3d_nms.boxes_iou3d_gpu
+
+    def forward(self, batch_dict):
+        c = self.cfg
+        rois, gt_of_rois, ious, scores, labels = self.sample_rois_for_rcnn(batch_dict)
+        reg_valid_mask = (ious > c["REG_FG_THRESH"]).long()
+        if c["CLS_SCORE_TYPE"] == "cls":
+            cls_labels = (ious > c["CLS_FG_THRESH"]).long()
+            cls_labels[(ious > c["CLS_BG_THRESH"]) & (ious < c["CLS_FG_THRESH"])] = -1
+        elif c["CLS_SCORE_TYPE"] == "roi_iou":
+            bg, fg = c["CLS_BG_THRESH"], c["CLS_FG_THRESH"]
+            fg_mask, bg_mask = ious > fg, ious < bg
+            interval = (fg_mask == 0) & (bg_mask == 0)
+            cls_labels = (fg_mask > 0).float()
+            cls_labels[interval] = (ious[interval] - bg) / (fg - bg)
+        else:
+            raise NotImplementedError(c["CLS_SCORE_TYPE"])
+        return {"rois": rois, "gt_of_rois": gt_of_rois, "gt_iou_of_rois": ious, "roi_scores": scores,
+                "roi_labels": labels, "reg_valid_mask": reg_valid_mask, "rcnn_cls_labels": cls_labels}
+
+    def sample_rois_for_rcnn(self, batch_dict):
+        B, n = batch_dict["batch_size"], self.cfg["ROI_PER_IMAGE"]
+        rois, roi_scores, roi_labels = batch_dict["rois"], batch_dict["roi_scores"], batch_dict["roi_labels"]
+        gt_boxes = batch_dict["gt_boxes_and_cls"]
+        code = rois.shape[-1]
+        out_rois, out_gt = rois.new_zeros(B, n, code), rois.new_zeros(B, n, code + 1)
+        out_iou, out_scores = rois.new_zeros(B, n), rois.new_zeros(B, n)
+        out_labels = rois.new_zeros((B, n), dtype=torch.long)
+        for i in range(B):
+            cur_gt = gt_boxes[i]
+            k = len(cur_gt) - 1
+            while k > 0 and cur_gt[k].sum() == 0:
+                k -= 1
+            cur_gt = cur_gt[: k + 1]
+            if len(cur_gt) == 0:
+                cur_gt = cur_gt.new_zeros((1, cur_gt.shape[1]))
+            if self.cfg.get("SAMPLE_ROI_BY_EACH_CLASS", False):
+                max_ov, assign = self.get_max_iou_with_same_class(rois[i][:, :7], roi_labels[i], cur_gt[:, 0:7],
+                                                                  cur_gt[:, -1].long())
+            else:
+                max_ov, assign = torch.max(self.iou_fn(rois[i], cur_gt[:, 0:7]), dim=1)
+            idx = self.subsample_rois(max_ov)
+            out_rois[i], out_labels[i], out_iou[i] = rois[i][idx], roi_labels[i][idx], max_ov[idx]
+            out_scores[i], out_gt[i] = roi_scores[i][idx], cur_gt[assign[idx]]
+        return out_rois, out_gt, out_iou, out_scores, out_labels
+
+    def subsample_rois(self, max_overlaps):
+        c = self.cfg
+        n = c["ROI_PER_IMAGE"]
+        fg_per_image = int(np.round(c["FG_RATIO"] * n))
+        fg_thresh = min(c["REG_FG_THRESH"], c["CLS_FG_THRESH"])
+        fg_inds = (max_overlaps >= fg_thresh).nonzero().view(-1)
+        easy_bg = (max_overlaps < c["CLS_BG_THRESH_LO"]).nonzero().view(-1)
+        hard_bg = ((max_overlaps < c["REG_FG_THRESH"]) & (max_overlaps >= c["CLS_BG_THRESH_LO"])).nonzero().view(-1)
+        n_fg, n_bg = fg_inds.numel(), hard_bg.numel() + easy_bg.numel()
+        dev = max_overlaps.device
+        if n_fg > 0 and n_bg > 0:
+            take = min(fg_per_image, n_fg)
+            perm = torch.from_numpy(np.random.permutation(n_fg)).long().to(dev)
+            fg_inds = fg_inds[perm[:take]]
+            bg_inds = self.sample_bg_inds(hard_bg, easy_bg, n - take, c["HARD_BG_RATIO"])
+        elif n_fg > 0 and n_bg == 0:
+            pick = torch.from_numpy(np.floor(np.random.rand(n) * n_fg)).long().to(dev)
+            fg_inds = fg_inds[pick]
+            bg_inds = fg_inds.new_zeros(0)
+        elif n_bg > 0 and n_fg == 0:
+            bg_inds = self.sample_bg_inds(hard_bg, easy_bg, n, c["HARD_BG_RATIO"])
+        else:
+            raise NotImplementedError("no foreground and no background RoI")
+        return torch.cat((fg_inds, bg_inds), dim=0)
+
+    @staticmethod
+    def sample_bg_inds(hard_bg, easy_bg, n_bg, hard_ratio):
+        def draw(pool, count):          # CPU generator, as the reference's device-less torch.randint
+            return pool[torch.randint(low=0, high=pool.numel(), size=(count,)).long().to(pool.device)]
+        if hard_bg.numel() > 0 and easy_bg.numel() > 0:
+            n_hard = min(int(n_bg * hard_ratio), len(hard_bg))
+            h = draw(hard_bg, n_hard)
+            return torch.cat([h, draw(easy_bg, n_bg - n_hard)], dim=0)
+        if hard_bg.numel() > 0:
+            return draw(hard_bg, n_bg)
+        if easy_bg.numel() > 0:
+            return draw(easy_bg, n_bg)
+        raise NotImplementedError
+
+    def get_max_iou_with_same_class(self, rois, roi_labels, gt_boxes, gt_labels):
+        max_ov = rois.new_zeros(rois.shape[0])
+        assign = roi_labels.new_zeros(roi_labels.shape[0])
+        for k in range(gt_labels.min().item(), gt_labels.max().item() + 1):
+            roi_mask, gt_mask = roi_labels == k, gt_labels == k
+            if roi_mask.sum() > 0 and gt_mask.sum() > 0:
+                orig = gt_mask.nonzero().view(-1)
+                cur_max, cur_assign = torch.max(self.iou_fn(rois[roi_mask], gt_boxes[gt_mask]), dim=1)
+                max_ov[roi_mask] = cur_max
+                assign[roi_mask] = orig[cur_assign]
+        return max_ov, assign
+
+
+def sigmoid_focal_loss(logits, target, weights, alpha=0.25, gamma=2.0):
+    """loss_utils.py:10-75 SigmoidFocalClassificationLoss.forward."""
+    p = torch.sigmoid(logits)
+    alpha_w = target * alpha + (1 - target) * (1 - alpha)
+    pt = target * (1.0 - p) + (1.0 - target) * p
+    bce = torch.clamp(logits, min=0) - logits * target + torch.log1p(torch.exp(-torch.abs(logits)))
+    loss = alpha_w * torch.pow(pt, gamma) * bce
+    if weights.dim() == 2 or (weights.dim() == 1 and target.dim() == 2):
+        weights = weights.unsqueeze(-1)
+    assert weights.dim() == loss.dim()
+    return loss * weights
 
 
 def _fc_stack(cfg_list, cin, cout, dp_ratio, conv=True):
@@ -209,6 +391,8 @@ class RoIMIXHead(nn.Module):
         self.shared_fc_layer = nn.Sequential(*shared)
         self.cls_layers = _fc_stack(list(model_cfg["CLS_FC"]), pre, num_class, model_cfg["DP_RATIO"])
         self.reg_layers = _fc_stack(list(model_cfg["REG_FC"]), pre, code_size, model_cfg["DP_RATIO"])
+        self.proposal_target_layer = ProposalTargetLayer(model_cfg["TARGET_CONFIG"]) if "TARGET_CONFIG" in model_cfg else None
+        self.use_iou, self.forward_ret_dict = False, None
         for m in self.modules():
             if isinstance(m, (nn.Conv2d, nn.Conv1d)):
                 nn.init.xavier_normal_(m.weight)
@@ -227,9 +411,76 @@ class RoIMIXHead(nn.Module):
         boxes[:, 0:3] += xyz
         return cls, boxes.view(batch_size, -1, code)
 
+    def assign_targets(self, batch_dict):
+        """roi_head_template.py:42-88: sample RoIs, then express each RoI's GT box in the RoI's own frame."""
+        B = batch_dict["batch_size"]
+        with torch.no_grad():
+            td = self.proposal_target_layer(batch_dict)
+        rois, gt = td["rois"], td["gt_of_rois"]
+        td["gt_of_rois_src"] = gt.clone().detach()
+        roi_ry = limit_period(rois[:, :, 6], offset=0.5, period=np.pi * 2)
+        gt[:, :, :6] = gt[:, :, :6] - rois[:, :, :6]
+        gt[:, :, 6] = gt[:, :, 6] - roi_ry
+        gt = rotate_points_along_z(gt.view(-1, 1, gt.shape[-1]), -roi_ry.view(-1)).view(B, -1, gt.shape[-1])
+        if rois.shape[-1] == 9:
+            gt[:, :, 7:-1] = gt[:, :, 7:-1] - rois[:, :, 7:]
+        heading = gt[:, :, 6] % (2 * np.pi)
+        opposite = (heading > np.pi * 0.5) & (heading < np.pi * 1.5)
+        heading[opposite] = (heading[opposite] + np.pi) % (2 * np.pi)
+        flag = heading > np.pi
+        heading[flag] = heading[flag] - np.pi * 2
+        gt[:, :, 6] = torch.clamp(heading, min=-np.pi / 2, max=np.pi / 2)
+        td["gt_of_rois"] = gt
+        return td
+
+    def get_loss(self, tb_dict=None):
+        """roi_head_template.py:90-187 (BinaryCrossEntropy / CrossEntropy class loss, L1 box loss)."""
+        tb = {} if tb_dict is None else tb_dict
+        ret, lc = self.forward_ret_dict, self.model_cfg["LOSS_CONFIG"]
+        w = lc["LOSS_WEIGHTS"]
+        labels = ret["rcnn_cls_labels"].view(-1)
+        valid = (labels >= 0).float()
+        if lc["CLS_LOSS"] == "BinaryCrossEntropy":
+            per = Fn.binary_cross_entropy(torch.sigmoid(ret["rcnn_cls"].view(-1)), labels.float(), reduction="none")
+        elif lc["CLS_LOSS"] == "CrossEntropy":
+            per = Fn.cross_entropy(ret["rcnn_cls"], labels, reduction="none", ignore_index=-1)
+        else:
+            raise NotImplementedError(lc["CLS_LOSS"])
+        loss_cls = (per * valid).sum() / torch.clamp(valid.sum(), min=1.0) * w["rcnn_cls_weight"]
+        if lc["REG_LOSS"] != "L1":
+            raise NotImplementedError(lc["REG_LOSS"])
+        code = ret["rcnn_reg"].shape[-1]
+        fg = ret["reg_valid_mask"].view(-1) > 0
+        target = ret["gt_of_rois"][..., 0:code].reshape(-1, code)
+        n = target.shape[0]
+        per = Fn.l1_loss(ret["rcnn_reg"].view(n, -1), target, reduction="none")
+        per = per * per.new_tensor(w["code_weights"])
+        loss_reg = (per.view(n, -1) * fg.unsqueeze(-1).float()).sum() / max(int(fg.long().sum().item()), 1)
+        loss_reg = loss_reg * w["rcnn_reg_weight"]
+        tb.update(rcnn_loss_cls=loss_cls.detach(), rcnn_loss_reg=loss_reg.detach())
+        total = loss_cls + loss_reg
+        tb["rcnn_loss"] = total.item()
+        return total, tb
+
+    def _forward_train(self, batch_dict):
+        """roi_mix_head.py:81-121 with training=True: the module path (BatchNorm statistics, Dropout)."""
+        td = batch_dict.get("roi_targets_dict", None)
+        if td is None:
+            td = self.assign_targets(batch_dict)
+            batch_dict["rois"], batch_dict["roi_labels"], batch_dict["roi_scores"] = td["rois"], td["roi_labels"], td["roi_scores"]
+        B, R = batch_dict["rois"].shape[:2]
+        feats = self.mlp_mixer(batch_dict["roi_features"].view(B * R, self.num_patches, -1))
+        if self.add_box_param:
+            feats = torch.cat([feats, batch_dict["rois"], batch_dict["roi_scores"].unsqueeze(-1)], dim=-1)
+        x = self.shared_fc_layer(feats.reshape(B * R, -1, 1))
+        td["rcnn_cls"] = self.cls_layers(x).transpose(1, 2).contiguous().squeeze(dim=1)
+        td["rcnn_reg"] = self.reg_layers(x).transpose(1, 2).contiguous().squeeze(dim=1)
+        self.forward_ret_dict = td
+        return batch_dict
+
     def forward(self, batch_dict, training=True):
         if training:
-            raise NotImplementedError("RoI head training (ProposalTargetLayer, losses) is not built")
+            return self._forward_train(batch_dict)
         B = len(batch_dict["rois"])
         R = batch_dict["rois"].shape[1]
         feats = self.mlp_mixer(batch_dict["roi_features"].view(B * R, self.num_patches, -1))
@@ -259,9 +510,50 @@ class PointHead(nn.Module):
         layers.append(nn.Linear(c_in, 1, bias=True))
         self.cls_layers = nn.Sequential(*layers)
 
+    def assign_targets(self, input_dict, in_boxes_fn=None):
+        """point_head_simple.py:23-60 + point_head_template.py:141-170: a grid point is foreground when it lies
+        inside the BEV rectangle of the GT box its RoI was matched to."""
+        pts = input_dict["point_coords"]
+        assert pts[0].shape[-1] == 2, "only the 2-D (RoI grid point) assignment is built"
+        gt = input_dict["roi_targets_dict"]["gt_of_rois_src"]
+        assert gt.dim() == 3 and gt.shape[2] == 8, f"gt_boxes.shape={tuple(gt.shape)}"
+        assert self.num_class == 1
+        fn = in_boxes_fn or points_in_boxes_2d
+        labels = []
+        for k in range(gt.shape[0]):
+            p = pts[k].contiguous()                                  # [rois, grid points, 2]
+            idx = fn(p, gt[k, :, 0:7].unsqueeze(dim=1).contiguous()).long()
+            lab = gt.new_zeros(p.shape[0], p.shape[1]).long()
+            lab[idx >= 0] = 1
+            labels.append(lab.view(-1))
+        return {"point_cls_labels": torch.cat(labels, dim=0)}
+
+    def get_loss(self, tb_dict=None):
+        """point_head_template.py:172-195 (sigmoid focal loss, normalised by the positives)."""
+        tb = {} if tb_dict is None else tb_dict
+        labels = self.forward_ret_dict["point_cls_labels"].view(-1)
+        preds = self.forward_ret_dict["point_cls_preds"].view(-1, self.num_class)
+        pos = labels > 0
+        w = ((labels == 0) * 1.0 + 1.0 * pos).float()
+        pos_norm = pos.sum(dim=0).float()
+        w = w / torch.clamp(pos_norm, min=1.0)
+        one_hot = preds.new_zeros(*labels.shape, self.num_class + 1)
+        one_hot.scatter_(-1, (labels * (labels >= 0).long()).unsqueeze(-1).long(), 1.0)
+        loss = sigmoid_focal_loss(preds, one_hot[..., 1:], w).sum()
+        loss = loss * self.model_cfg["LOSS_CONFIG"]["LOSS_WEIGHTS"]["point_cls_weight"]
+        tb.update(point_loss_cls=loss.item(), point_pos_num=pos_norm.item())
+        return loss, tb
+
     def forward(self, batch_dict):
         if self.training:
-            raise NotImplementedError("point-head target assignment / loss is not built")
+            pf = batch_dict["point_features"]
+            preds = self.cls_layers(pf.reshape(-1, pf.shape[-1]))
+            batch_dict["point_cls_scores"] = torch.sigmoid(preds)
+            if self.model_cfg.get("ATT_MODEL", False):
+                batch_dict["point_features"] = pf * batch_dict["point_cls_scores"].view(*pf.shape[:-1], 1)
+            self.forward_ret_dict = {"point_cls_preds": preds,
+                                     "point_cls_labels": self.assign_targets(batch_dict)["point_cls_labels"]}
+            return batch_dict
         pf = batch_dict["point_features"]
         mlp = dense_hip.PLANS.get(self, lambda m: FoldedMLP(m.cls_layers))
         batch_dict["point_cls_scores"] = torch.sigmoid(mlp(pf.reshape(-1, pf.shape[-1]).float()))
@@ -319,19 +611,39 @@ class PillarRCNN(BaseDetector):
         example.update(rois=rois, roi_labels=labels, roi_scores=scores, has_class_labels=True)
         return example
 
+    def combine_loss(self, one_stage_loss, point_loss, roi_loss, tb_dict):
+        """pillar_rcnn.py:44-50."""
+        for _ in range(len(one_stage_loss["loss"])):
+            one_stage_loss["roi_reg_loss"].append(tb_dict["rcnn_loss_reg"])
+            one_stage_loss["roi_cls_loss"].append(tb_dict["rcnn_loss_cls"])
+        one_stage_loss["loss"][0] = one_stage_loss["loss"][0] + roi_loss + point_loss
+        return one_stage_loss
+
     def forward(self, example, return_loss=True, **kwargs):
-        if return_loss:
-            raise NotImplementedError("Pillar R-CNN training is not built (first stage trains through PillarNet)")
+        """pillar_rcnn.py:85-131."""
         example = dict(example)
         example["batch_size"] = len(example["metadata"])
-        boxes, bev, backbone_features, _ = self.single_det.forward_two_stage(example, False, **kwargs)
+        boxes, bev, backbone_features, one_stage_loss = self.single_det.forward_two_stage(example, return_loss, **kwargs)
         example["bev_feature"], example["backbone_features"] = bev[-1], backbone_features
+        if self.roi_head.code_size == 7 and return_loss:
+            example["gt_boxes_and_cls"] = example["gt_boxes_and_cls"][:, :, [0, 1, 2, 3, 4, 5, 6, -1]]   # drop velocity
         example = self.reorder_first_stage_prediction(boxes, example)
+        if self.training:
+            td = self.roi_head.assign_targets(example)
+            example["rois"], example["roi_labels"], example["roi_scores"] = td["rois"], td["roi_labels"], td["roi_scores"]
+            example["roi_targets_dict"] = td
         for module in self.second_stage:
             example = module(example)
         if self.point_head is not None:
             example = self.point_head(example)
-        return self.post_process(self.roi_head(example, training=False))
+        batch_dict = self.roi_head(example, training=return_loss)
+        if not return_loss:
+            return self.post_process(batch_dict)
+        roi_loss, tb = self.roi_head.get_loss()
+        point_loss = 0
+        if self.point_head is not None:
+            point_loss, tb = self.point_head.get_loss(tb)
+        return self.combine_loss(one_stage_loss, point_loss, roi_loss, tb)
 
     def post_process(self, batch_dict):
         """pillar_rcnn.py:133-166: score = sqrt(sigmoid(cls) * roi_score); no second NMS."""

@@ -51,12 +51,15 @@ def assign_labels(gt_boxes, gt_classes, tasks, pc_range, pillar_size, gaussian_o
     grid = np.round((pc_range[3:5] - pc_range[:2]) / ps).astype(np.int64)
     out = dict(hm=[], anno_box=[], ind=[], mask=[], cat=[], gt_box=[])
     flag = 0
+    flat_boxes, flat_cls = [], []      # "used for two stage code", preprocess.py:324-343
     for task in tasks:
         names, stride = task["class_names"], int(task["stride"])
         sel = [np.where(gt_classes == i + 1 + flag)[0] for i in range(len(names))]
         boxes = np.concatenate([gt_boxes[s] for s in sel], axis=0).astype(np.float32).copy()
         cls = np.concatenate([gt_classes[s] - flag for s in sel])
         boxes[:, -1] = limit_period(boxes[:, -1], offset=0.5, period=np.pi * 2)
+        flat_boxes.append(boxes)
+        flat_cls.append(cls + flag)
         g = grid // stride
         hm = np.zeros((len(names), g[1], g[0]), np.float32)
         anno = np.zeros((max_objs, 10), np.float32)
@@ -89,6 +92,12 @@ def assign_labels(gt_boxes, gt_classes, tasks, pc_range, pillar_size, gaussian_o
         out["cat"].append(cat)
         out["gt_box"].append(gtb)
         flag += len(names)
+    # x, y, z, w, l, h, rotation_y, velocity_x, velocity_y, class (1-based over all tasks); zero rows pad
+    both = np.concatenate((np.concatenate(flat_boxes, 0), np.concatenate(flat_cls).reshape(-1, 1).astype(np.float32)), 1)
+    assert len(both) <= max_objs
+    gbc = np.zeros((max_objs, 10), np.float32)
+    gbc[: len(both)] = both[:, [0, 1, 2, 3, 4, 5, 8, 6, 7, 9]]
+    out["gt_boxes_and_cls"] = gbc
     return out
 
 
@@ -121,4 +130,6 @@ def collate(samples, device):
     for key in ("hm", "anno_box", "ind", "mask", "cat", "gt_box"):
         ntask = len(samples[0][key])
         ex[key] = [torch.as_tensor(np.stack([s[key][t] for s in samples])).to(device) for t in range(ntask)]
+    if "gt_boxes_and_cls" in samples[0]:
+        ex["gt_boxes_and_cls"] = torch.as_tensor(np.stack([s["gt_boxes_and_cls"] for s in samples])).to(device)
     return ex

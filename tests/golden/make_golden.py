@@ -14,6 +14,7 @@ Reference code executed here (imported from /root/reference, nothing copied):
   det3d.models.second_stage.BEVStrideFeature, roi_heads.RoIMIXHead, point_heads.PointHead,
   detectors.pillar_rcnn.PillarRCNN.post_process       -> rcnn.npz
   det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz
+  roi_heads ProposalTargetLayer / RoIHeadTemplate.assign_targets + get_loss, PointHead targets + loss -> rcnn_train.npz
 
 The reference imports packages this image lacks (numba, addict, spconv, torchvision, terminaltables,
 its own un-built CUDA extensions); they are replaced by inert in-process module objects so that the
@@ -359,6 +360,7 @@ def golden_train(head):
     for key in ("hm", "anno_box", "ind", "mask", "cat", "gt_box"):
         for t in range(2):
             arrays[f"al.{key}.{t}"] = np.asarray(tg[key][t])
+    arrays["al.gt_boxes_and_cls"] = np.asarray(tg["gt_boxes_and_cls"])
     # losses
     torch.manual_seed(5)
     B, H, W, K = 2, 16, 20, 50
@@ -470,6 +472,108 @@ def golden_rcnn():
     save("rcnn.npz", **arrays)
 
 
+def golden_rcnn_train():
+    """Training side of the second stage on CPU: ProposalTargetLayer (its np.random / torch RNG calls under
+    fixed seeds), RoIHeadTemplate.assign_targets + get_loss, PointHeadTemplate.assign_stack_targets_2d +
+    get_cls_layer_loss.  The two CUDA-only helpers are served by restatements: boxes_iou3d_gpu by the
+    reference's own torch code around the compiled-reference-pinned BEV overlap (oracle/iou3d), and
+    points_in_boxes_2d_gpu by a numpy loop over roiaware_pool3d_kernel.cu:39-50 (that kernel is unpinned)."""
+    from oracle import iou3d
+    import det3d.ops.iou3d_nms.iou3d_nms_utils as iu
+    import det3d.ops.roiaware_pool3d.roiaware_pool3d_utils as ru
+    from det3d.models.roi_heads.roi_mix_head import RoIMIXHead
+    import det3d.models.roi_heads.target_assigner.proposal_target_layer as ptl
+    from det3d.models.point_heads.point_head_simple import PointHead
+    from det3d.torchie import Config
+
+    def boxes_iou3d_cpu(a, b):
+        a, b = iu.to_pcdet(a), iu.to_pcdet(b)
+        ov = torch.from_numpy(iou3d.iou_matrix(a.numpy(), b.numpy(), overlap_only=True)).float()
+        hmax = torch.min((a[:, 2] + a[:, 5] / 2).view(-1, 1), (b[:, 2] + b[:, 5] / 2).view(1, -1))
+        hmin = torch.max((a[:, 2] - a[:, 5] / 2).view(-1, 1), (b[:, 2] - b[:, 5] / 2).view(1, -1))
+        o3 = ov * torch.clamp(hmax - hmin, min=0)
+        va, vb = (a[:, 3] * a[:, 4] * a[:, 5]).view(-1, 1), (b[:, 3] * b[:, 4] * b[:, 5]).view(1, -1)
+        return o3 / torch.clamp(va + vb - o3, min=1e-6)
+
+    def points_in_boxes_2d_cpu(points, boxes):
+        boxes = iu.to_pcdet(boxes.reshape(-1, 7)).reshape(boxes.shape).numpy().astype(np.float32)
+        pts = points.numpy().astype(np.float32)
+        out = np.full(pts.shape[:2], -1, np.int32)
+        for b in range(pts.shape[0]):
+            for k in range(boxes.shape[1] - 1, -1, -1):
+                q = boxes[b, k]
+                sx, sy = pts[b, :, 0] - q[0], pts[b, :, 1] - q[1]
+                ca, sa = np.float32(np.cos(-q[6])), np.float32(np.sin(-q[6]))
+                lx, ly = sx * ca + sy * (-sa), sx * sa + sy * ca
+                hit = (np.abs(lx.astype(np.float64)) < np.float64(q[3]) / 2.0 + np.float64(np.float32(1e-5))) & \
+                      (np.abs(ly.astype(np.float64)) < np.float64(q[4]) / 2.0 + np.float64(np.float32(1e-5)))
+                out[b, hit] = k
+        return torch.from_numpy(out)
+
+    ptl.boxes_iou3d_gpu = boxes_iou3d_cpu
+    ru.points_in_boxes_2d_gpu = points_in_boxes_2d_cpu
+    g = torch.Generator().manual_seed(41)
+    B, R, G_ = 2, 60, 9
+    gt = torch.zeros(B, 12, 8)
+    gt[:, :G_, 0:2] = (torch.rand(B, G_, 2, generator=g) - 0.5) * 40
+    gt[:, :G_, 2] = torch.randn(B, G_, generator=g) * 0.3
+    gt[:, :G_, 3:6] = torch.rand(B, G_, 3, generator=g) * torch.tensor([1.5, 3.0, 1.0]) + torch.tensor([1.2, 2.5, 1.2])
+    gt[:, :G_, 6] = (torch.rand(B, G_, generator=g) - 0.5) * 6.2
+    gt[:, :G_, 7] = torch.randint(1, 4, (B, G_), generator=g).float()
+    rois = torch.zeros(B, R, 7)
+    src = torch.randint(0, G_, (B, R), generator=g)
+    for b in range(B):
+        rois[b] = gt[b, src[b], :7]
+    jitter = torch.rand(B, R, 1, generator=g) ** 2            # from near-perfect to far-off proposals
+    rois[..., 0:2] += torch.randn(B, R, 2, generator=g) * 1.5 * jitter
+    rois[..., 3:6] *= 1 + torch.randn(B, R, 3, generator=g) * 0.15 * jitter
+    rois[..., 6] += torch.randn(B, R, generator=g) * 0.3 * jitter[..., 0]
+    labels = torch.zeros(B, R, dtype=torch.long)
+    for b in range(B):
+        labels[b] = gt[b, src[b], 7].long()
+    labels[:, -6:] = torch.randint(1, 4, (B, 6), generator=g)   # some proposals carry another class
+    scores = torch.rand(B, R, generator=g)
+    cfg = Config(dict(CLASS_AGNOSTIC=True, SHARED_FC=[32, 32], CLS_FC=[32, 32], REG_FC=[32, 32], DP_RATIO=0.3,
+                      TARGET_CONFIG=dict(ROI_PER_IMAGE=32, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                         CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.7, CLS_BG_THRESH=0.25,
+                                         CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.5),
+                      LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="L1",
+                                       LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0,
+                                                         code_weights=[1.0] * 7))))._cfg_dict
+    head = RoIMIXHead(in_channels=4, model_cfg=cfg, code_size=7, mixer_type="", num_patches=49).train()
+    batch = dict(batch_size=B, rois=rois.clone(), roi_scores=scores.clone(), roi_labels=labels.clone(),
+                 gt_boxes_and_cls=gt.clone())
+    np.random.seed(7)
+    torch.manual_seed(8)
+    td = head.assign_targets(batch)
+    arrays = {"in.rois": rois.numpy(), "in.roi_scores": scores.numpy(), "in.roi_labels": labels.numpy(),
+              "in.gt_boxes_and_cls": gt.numpy()}
+    for k in ("rois", "gt_of_rois", "gt_of_rois_src", "gt_iou_of_rois", "roi_scores", "roi_labels", "reg_valid_mask",
+              "rcnn_cls_labels"):
+        arrays["pt." + k] = td[k].numpy()
+    M = td["rois"].shape[1]
+    rcnn_cls, rcnn_reg = torch.randn(B * M, 1, generator=g), torch.randn(B * M, 7, generator=g) * 0.3
+    td["rcnn_cls"], td["rcnn_reg"] = rcnn_cls, rcnn_reg
+    head.forward_ret_dict = td
+    loss, tb = head.get_loss()
+    arrays.update({"loss.in.rcnn_cls": rcnn_cls.numpy(), "loss.in.rcnn_reg": rcnn_reg.numpy(),
+                   "loss.total": np.asarray(float(loss)), "loss.cls": np.asarray(float(tb["rcnn_loss_cls"])),
+                   "loss.reg": np.asarray(float(tb["rcnn_loss_reg"]))})
+    # point head: grid points of the sampled RoIs against their assigned GT boxes
+    pcfg = Config(dict(CLASS_AGNOSTIC=True, CLS_FC=[32, 32], TARGET_CONFIG=dict(GT_EXTRA_WIDTH=[0.2, 0.2, 0.2]),
+                       LOSS_CONFIG=dict(LOSS_REG="smooth-l1", LOSS_WEIGHTS=dict(point_cls_weight=1.0))))._cfg_dict
+    ph = PointHead(in_channels=4, num_class=1, model_cfg=pcfg).train()
+    pts = td["rois"][..., None, 0:2] + torch.randn(B, M, 49, 2, generator=g) * 1.2
+    tgt = ph.assign_targets(dict(point_coords=pts, roi_targets_dict=td))
+    preds = torch.randn(B * M * 49, 1, generator=g)
+    ph.forward_ret_dict = dict(point_cls_preds=preds, point_cls_labels=tgt["point_cls_labels"])
+    pl, ptb = ph.get_loss()
+    arrays.update({"ph.in.point_coords": pts.numpy(), "ph.point_cls_labels": tgt["point_cls_labels"].numpy(),
+                   "ph.in.preds": preds.numpy(), "ph.loss": np.asarray(float(pl)),
+                   "ph.pos_num": np.asarray(float(ptb["point_pos_num"]))})
+    save("rcnn_train.npz", **arrays)
+
+
 def golden_loading():
     """LoadPointCloudFromFile (nuScenes branch) / read_sweep of the reference on .bin sweeps written to a
     temporary directory from seeded arrays; the fixture keeps the arrays, the transforms, the order the
@@ -528,3 +632,4 @@ if __name__ == "__main__":
     golden_train(head)
     golden_rcnn()
     golden_loading()
+    golden_rcnn_train()

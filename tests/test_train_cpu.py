@@ -40,6 +40,8 @@ def test_assign_labels_matches_reference():
             else:
                 np.testing.assert_array_equal(got, want)
     assert sum(int(G[f"al.mask.{t}"].sum()) for t in range(2)) >= 8
+    # the two-stage target (preprocess.py:324-343): all boxes task by task, heading at column 6, class last
+    np.testing.assert_allclose(out["gt_boxes_and_cls"], G["al.gt_boxes_and_cls"], rtol=1e-6, atol=1e-6)
 
 
 def _t(k):
@@ -116,3 +118,69 @@ def test_allreduce_grads_two_ranks_gloo():
     for _, gw, gb in res:
         np.testing.assert_allclose(gw, 3.0)
         np.testing.assert_allclose(gb, 2.0)
+
+
+def _rcnn_train_golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "rcnn_train.npz"))
+
+
+def _oracle_iou3d(a, b):
+    """boxes_iou3d_gpu (iou3d_nms_utils.py:37-74) around the compiled-reference-pinned BEV overlap."""
+    from oracle import iou3d
+    from pillarnet_lts_amd.iou3d_nms import to_pcdet
+    a, b = to_pcdet(a), to_pcdet(b)
+    ov = torch.from_numpy(iou3d.iou_matrix(a.numpy(), b.numpy(), overlap_only=True)).float()
+    hmax = torch.min((a[:, 2] + a[:, 5] / 2).view(-1, 1), (b[:, 2] + b[:, 5] / 2).view(1, -1))
+    hmin = torch.max((a[:, 2] - a[:, 5] / 2).view(-1, 1), (b[:, 2] - b[:, 5] / 2).view(1, -1))
+    o3 = ov * torch.clamp(hmax - hmin, min=0)
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5]).view(-1, 1), (b[:, 3] * b[:, 4] * b[:, 5]).view(1, -1)
+    return o3 / torch.clamp(va + vb - o3, min=1e-6)
+
+
+RCNN_TRAIN_CFG = dict(CLASS_AGNOSTIC=True, SHARED_FC=[32, 32], CLS_FC=[32, 32], REG_FC=[32, 32], DP_RATIO=0.3,
+                      TARGET_CONFIG=dict(ROI_PER_IMAGE=32, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                         CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.7, CLS_BG_THRESH=0.25,
+                                         CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.5),
+                      LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="L1",
+                                       LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0,
+                                                         code_weights=[1.0] * 7)))
+
+
+def test_proposal_targets_and_roi_losses_match_reference():
+    """ProposalTargetLayer + RoI head target encoding + losses against the reference's own modules run on CPU
+    under the same numpy / torch seeds (tests/golden/rcnn_train.npz)."""
+    from pillarnet_lts_amd import second_stage
+    from pillarnet_lts_amd.config import ConfigDict
+    g = _rcnn_train_golden()
+    head = second_stage.RoIMIXHead(in_channels=4, model_cfg=ConfigDict(RCNN_TRAIN_CFG), code_size=7, mixer_type="",
+                                   num_patches=49).train()
+    head.proposal_target_layer.iou_fn = _oracle_iou3d
+    t = lambda k: torch.from_numpy(g[k])
+    batch = dict(batch_size=2, rois=t("in.rois"), roi_scores=t("in.roi_scores"), roi_labels=t("in.roi_labels"),
+                 gt_boxes_and_cls=t("in.gt_boxes_and_cls"))
+    np.random.seed(7)
+    torch.manual_seed(8)
+    td = head.assign_targets(batch)
+    for k in ("rois", "roi_scores", "roi_labels", "reg_valid_mask", "gt_of_rois_src"):
+        np.testing.assert_array_equal(td[k].numpy(), g["pt." + k], err_msg=k)
+    for k in ("gt_iou_of_rois", "rcnn_cls_labels", "gt_of_rois"):
+        np.testing.assert_allclose(td[k].numpy(), g["pt." + k], rtol=1e-6, atol=1e-6, err_msg=k)
+    td["rcnn_cls"], td["rcnn_reg"] = t("loss.in.rcnn_cls"), t("loss.in.rcnn_reg")
+    head.forward_ret_dict = td
+    loss, tb = head.get_loss()
+    np.testing.assert_allclose(float(loss), float(g["loss.total"]), rtol=1e-6)
+    np.testing.assert_allclose(float(tb["rcnn_loss_cls"]), float(g["loss.cls"]), rtol=1e-6)
+    np.testing.assert_allclose(float(tb["rcnn_loss_reg"]), float(g["loss.reg"]), rtol=1e-6)
+
+
+def test_point_head_focal_loss_matches_reference():
+    from pillarnet_lts_amd import second_stage
+    from pillarnet_lts_amd.config import ConfigDict
+    g = _rcnn_train_golden()
+    ph = second_stage.PointHead(in_channels=4, num_class=1, model_cfg=ConfigDict(
+        CLS_FC=[32, 32], LOSS_CONFIG=dict(LOSS_REG="smooth-l1", LOSS_WEIGHTS=dict(point_cls_weight=1.0))))
+    ph.forward_ret_dict = dict(point_cls_preds=torch.from_numpy(g["ph.in.preds"]),
+                               point_cls_labels=torch.from_numpy(g["ph.point_cls_labels"]))
+    loss, tb = ph.get_loss()
+    np.testing.assert_allclose(float(loss), float(g["ph.loss"]), rtol=1e-6)
+    assert tb["point_pos_num"] == float(g["ph.pos_num"])
