@@ -169,6 +169,20 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   const int lw = wave - NWC;                   // loader index (pieces are dealt round-robin over NWL)
   GGW_STAMP(wave == 0, 0);
 
+  // the rulebook tile and scale / shift first: their round trip (the longest latency of the prologue) runs
+  // under the descriptor / lane-offset setup and the first weight DMA below
+  int nb[(9 * BM + NT - 1) / NT];
+#pragma unroll
+  for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {   // all loads in flight before the first use
+    const int q = tid + j * NT, tap = q / BM, r = q - tap * BM, m = m0 + r;
+    nb[j] = (q < 9 * BM && m < M) ? a.nbr[(size_t)tap * a.nbr_stride + m] : -1;
+  }
+  float scv = 0.f, shv = 0.f;
+  if (tid < BN && n0 + tid < a.cout_total) {
+    scv = a.scale[n0 + tid];
+    shv = a.shift[n0 + tid];
+  }
+
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.wt, 0, (int)((size_t)9 * a.cout_total * a.cin * 2), 0x00020000);
@@ -207,17 +221,6 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   if (tid < 2 * RPP * CH) {   // RPP zero rows in each of the two window buffers
     const int b = tid / (RPP * CH), q = tid - b * (RPP * CH);
     *reinterpret_cast<uint4*>(smem + b * ABUF + WMAX * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
-  }
-  int nb[(9 * BM + NT - 1) / NT];
-#pragma unroll
-  for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {   // all loads in flight before the first use
-    const int q = tid + j * NT, tap = q / BM, r = q - tap * BM, m = m0 + r;
-    nb[j] = (q < 9 * BM && m < M) ? a.nbr[(size_t)tap * a.nbr_stride + m] : -1;
-  }
-  float scv = 0.f, shv = 0.f;
-  if (tid < BN && n0 + tid < a.cout_total) {
-    scv = a.scale[n0 + tid];
-    shv = a.shift[n0 + tid];
   }
 #pragma unroll
   for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {
