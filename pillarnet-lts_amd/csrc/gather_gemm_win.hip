@@ -562,7 +562,12 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
     return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
   // 8 compute waves of 64 x 64 + 8 loaders: measured 2-6 % ahead of 4 x (64 x 128) + 4 on every 256-wide shape
+  // small maps (a 90 x 90 level is 64 tiles of 128 rows on 256 CUs): 64 x 128 tiles fill the chip, and with
+  // unit stages (a kernel row's three weight tiles fit: 6 x 16 KB) a tile has 12 barriers instead of 36
+  if ((f == 'Q' || (f != 'A' && (long long)a.rows * groups <= 128 * 160)) && N % 128 == 0)
+    return launch_win<64, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);   // (160: a stride-2 run is 2*64+3 rows)
   if (f == 'D') return launch_win<128, 256, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
+  if (f == 'U') return launch_win<128, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);
   if (f == 'M') return launch_win<256, 128, 4, 2, 8, 64, 320, TOut>(a, groups, stream);
   return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
 }
