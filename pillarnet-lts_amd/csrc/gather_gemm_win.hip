@@ -552,6 +552,8 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   if (N <= 64) {
     if (f == 'H') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut>(a, groups, stream);   // two workgroups per CU
     if (f == 'I') return launch_win<128, 64, 4, 1, 4, 64, 160, TOut>(a, groups, stream);   // ... with 32 x 64 wave tiles
+    if (unit && (long long)a.rows * groups <= 256 * 200)   // fewer 256-row tiles than CUs: halve them
+      return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
     return unit ? launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                 : launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
