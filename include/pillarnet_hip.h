@@ -245,12 +245,15 @@ int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_rows, const 
 /* Grouped form of pn_gather_gemm: `groups` problems over the same rows / rulebook; group g reads the
  * channel slice starting at in + g*in_group_cols, uses weight + g*ntaps*cout*cin and
  * scale/shift + g*cout, and writes out + g*out_group_cols.  (CenterHead's per-task output convs,
- * det3d/models/bbox_heads/center_head.py:31-32,101-112, in one launch.) */
+ * det3d/models/bbox_heads/center_head.py:31-32,101-112, in one launch.)  out_rows (optional): output
+ * row of site m for group g = out_rows[g*out_rows_group_stride + m] -- the four parity GEMMs of a
+ * ConvTranspose2d(k2, s2) (det3d/models/necks/rpn.py:160-170) as one launch. */
 int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows, int in_group_cols,
                            const int32_t* nbr, int nbr_stride, int ntaps, int rows,
                            const void* weight, int cout, int groups, const float* scale,
                            const float* shift, int relu, void* out, int out_ld,
-                           int out_group_cols, int out_fp32, pnStream stream);
+                           int out_group_cols, int out_fp32, const int32_t* out_rows,
+                           long long out_rows_group_stride, pnStream stream);
 
 /* Spatial half of a 3x3 conv whose per-tap channel products z = x . [W_0 | ... | W_8] were computed
  * first (as a 1-tap GEMM): out[p, c] = bias[c] + sum_tap z[nbr[tap][p], tap*channels + c], fp32.

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
     a.scale += g * a.g_ss;
     a.shift += g * a.g_ss;
     a.out = reinterpret_cast<char*>(a.out) + g * a.g_out * (long long)sizeof(TOut);
+    if (a.out_rows) a.out_rows += g * a.g_rows;
   }
   int M = a.count ? *a.count : a.rows;
   if (M > a.rows) M = a.rows;
@@ -427,7 +428,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
-  a.g_in = a.g_wt = a.g_ss = a.g_out = 0;
+  a.g_in = a.g_wt = a.g_ss = a.g_out = a.g_rows = 0;
   { const char* d = getenv("PN_GG_DIAG"); a.diag = d ? atoi(d) : 0; }
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   {
@@ -444,7 +445,8 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
                                       const int32_t* nbr, int nbr_stride, int ntaps, int rows,
                                       const void* weight, int cout, int groups, const float* scale,
                                       const float* shift, int relu, void* out, int out_ld,
-                                      int out_group_cols, int out_fp32, pnStream stream_) {
+                                      int out_group_cols, int out_fp32, const int32_t* out_rows,
+                                      long long out_rows_group_stride, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(in && weight && scale && shift && out && groups >= 1 && rows >= 1,
                "pn_gather_gemm_grouped: bad argument");
@@ -457,8 +459,9 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
   a.nbr_stride = nbr_stride; a.count = nullptr;
   a.rows = rows; a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
-  a.out = out; a.out_ld = out_ld; a.out_rows = nullptr;
+  a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
   a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
+  a.g_rows = out_rows_group_stride;
   a.diag = 0;
   {
     const int rc = pn_gg_try_window(a, groups, out_fp32 != 0, stream);

@@ -148,6 +148,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     a.scale += g * a.g_ss;
     a.shift += g * a.g_ss;
     a.out = reinterpret_cast<char*>(a.out) + g * a.g_out * (long long)sizeof(TOut);
+    if (a.out_rows) a.out_rows += g * a.g_rows;
   }
   int M = a.count ? *a.count : a.rows;
   if (M > a.rows) M = a.rows;

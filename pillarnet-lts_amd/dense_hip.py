@@ -57,8 +57,8 @@ def up2_rows(B, H, W, device):
     for dy in range(2):
         for dx in range(2):
             maps.append(((b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx).reshape(-1).to(torch.int32))
-    _RULES[key] = maps
-    return maps
+    _RULES[key] = torch.stack(maps).contiguous()           # [4, rows_in]
+    return _RULES[key]
 
 
 class Rows:
@@ -141,31 +141,35 @@ class ConvStep:
 
 
 class UpStep:
-    """ConvTranspose2d(k2, s2, no bias) [+ BN] [+ ReLU]: four 1-tap GEMMs, one per output parity."""
+    """ConvTranspose2d(k2, s2, no bias) [+ BN] [+ ReLU]: four 1-tap GEMMs, one per output parity, issued as
+    ONE grouped launch (group = parity: its own weight slice and output-row map, the same input rows)."""
 
     def __init__(self, convt, bn, relu):
         assert convt.kernel_size == (2, 2) and convt.stride == (2, 2) and convt.padding == (0, 0)
         self.cin, self.cout, self.relu = convt.in_channels, convt.out_channels, relu
         with torch.no_grad():
             w = convt.weight.detach()                      # [cin, cout, 2, 2]
-            self.w = [w[:, :, dy, dx].t().reshape(1, self.cout, self.cin).to(torch.bfloat16).contiguous()
-                      for dy in range(2) for dx in range(2)]
+            self.w = torch.stack([w[:, :, dy, dx].t().reshape(1, self.cout, self.cin)
+                                  for dy in range(2) for dx in range(2)]).to(torch.bfloat16).contiguous()
             if bn is not None:
-                self.scale, self.shift = fold_batchnorm(bn, convt.bias)
+                scale, shift = fold_batchnorm(bn, convt.bias)
             else:
-                self.scale = torch.ones(self.cout, device=w.device)
-                self.shift = torch.zeros(self.cout, device=w.device)
+                scale = torch.ones(self.cout, device=w.device)
+                shift = torch.zeros(self.cout, device=w.device)
+            self.scale, self.shift = scale.repeat(4).contiguous(), shift.repeat(4).contiguous()
 
     def run(self, x: Rows, out=None):
         assert x.t.shape[1] == self.cin
-        maps = up2_rows(x.B, x.H, x.W, x.t.device)
+        maps = up2_rows(x.B, x.H, x.W, x.t.device)         # [4, rows_in] int32
         rows_in = x.B * x.H * x.W
         if out is None:
             out = torch.empty((rows_in * 4, self.cout), dtype=torch.bfloat16, device=x.t.device)
         assert out.shape == (rows_in * 4, self.cout) and out.stride(1) == 1
-        for p in range(4):
-            _launch(x.t, self.cin, None, 1, rows_in, self.w[p], self.scale, self.shift, self.relu, out,
-                    out.stride(0), out_rows=maps[p], in_ld=x.ld)
+        rc = _lib.lib().pn_gather_gemm_grouped(_lib.ptr(x.t), self.cin, x.ld, x.t.shape[0], 0, None, 0, 1, rows_in,
+                                               _lib.ptr(self.w), self.cout, 4, _lib.ptr(self.scale),
+                                               _lib.ptr(self.shift), int(self.relu), _lib.ptr(out), out.stride(0), 0, 0,
+                                               _lib.ptr(maps), rows_in, _lib.current_stream(x.t.device))
+        _lib.check(rc, "pn_gather_gemm_grouped")
         return Rows(out, x.B, 2 * x.H, 2 * x.W)
 
 
@@ -348,7 +352,7 @@ class HeadPlan:
                 maps = torch.empty((G, rows, npad), dtype=torch.float32, device=dev)
                 rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, _lib.ptr(nbr), nbr.shape[1], 9,
                                               rows, _lib.ptr(w9), npad, G, _lib.ptr(one), _lib.ptr(bias), 0,
-                                              _lib.ptr(maps), npad, rows * npad, 1, _lib.current_stream(dev))
+                                              _lib.ptr(maps), npad, rows * npad, 1, None, 0, _lib.current_stream(dev))
                 _lib.check(rc, "pn_gather_gemm_grouped")
                 for g, (t, _k0, _kin, nout, _npad, _wt, _ones, _bias) in enumerate(task_convs):
                     out[t] = (maps[g], nout, npad, x.B, Ho, Wo)
@@ -359,7 +363,7 @@ class HeadPlan:
                 z = torch.empty((rows, G * 9 * npad), dtype=torch.float32, device=dev)
                 rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, None, 0, 1, rows,
                                               _lib.ptr(wz), 9 * npad, G, _lib.ptr(ones), _lib.ptr(zeros), 0,
-                                              _lib.ptr(z), G * 9 * npad, 9 * npad, 1, _lib.current_stream(dev))
+                                              _lib.ptr(z), G * 9 * npad, 9 * npad, 1, None, 0, _lib.current_stream(dev))
                 _lib.check(rc, "pn_gather_gemm_grouped")
                 maps = torch.empty((G, rows, npad), dtype=torch.float32, device=dev)
                 rc = L.pn_tap_sum(_lib.ptr(z), G * 9 * npad, 9 * npad, _lib.ptr(nbr), nbr.shape[1], rows, npad, G,
