@@ -106,10 +106,10 @@ extern "C" int pn_gg_win_debug_stamps(unsigned long long* host_out, int n) {
 }
 
 // LDS pool = the staging buffers (2 windows + 3 weight tiles), or the parked fp32 output tile if larger
-template <int BM, int BN, int BK, int WMAX, bool UNIT>
+template <int BM, int BN, int BK, int WMAX, bool UNIT, int RING>
 constexpr int win_pool_bytes() {
   constexpr int RPP = 1024 / (BK * 2);
-  constexpr int staging = 2 * (WMAX + RPP) * BK * 2 + (UNIT ? 6 : 3) * BN * BK * 2;
+  constexpr int staging = 2 * (WMAX + RPP) * BK * 2 + (UNIT ? 6 : RING) * BN * BK * 2;
   constexpr int parked = BM * (BN * 4 + 16);
   return staging > parked ? staging : parked;
 }
@@ -117,7 +117,9 @@ constexpr int win_pool_bytes() {
 // UNIT (narrow layers, where a tap's weight tile is small): in window mode a stage is a whole kernel row --
 // its three taps' weights land together, double-buffered -- so a tile has 3*kchunks barriers instead of
 // 9*kchunks; a 16-MFMA stage spent more time on its barrier and first LDS reads than on its MFMAs.
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT>
+// RING: weight tiles in flight + in use on the per-tap path: 3 (two stages ahead, counted vmcnt) or 2 (one
+// ahead; the smaller pool lets two workgroups share a CU and cover each other's barriers instead).
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT, int RING>
 __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a, int force_gather) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no __amdgpu_buffer_rsrc_t to check the helpers against
   constexpr int NWC = NWM * NWN;              // compute waves; waves NWC .. NWC+NWL-1 are loaders
@@ -129,7 +131,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int ABUF = (WMAX + RPP) * ROWB;   // window + one piece of zero rows (row WMAX = "no neighbour")
   constexpr int WBUF = BN * ROWB;
-  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX, UNIT>();   // staging buffers; the epilogue parks the fp32 tile here
+  static_assert(RING == 2 || RING == 3, "weight ring of 2 or 3");
+  static_assert(!UNIT || RING == 3, "unit kernels keep the 3-deep ring for their gather-mode tiles");
+  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>();   // staging buffers; the epilogue parks the fp32 tile here
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
   static_assert(NWM * NWN + NWL >= 3, "three waves reduce the rulebook tile");
   static_assert(WMAX % RPP == 0 && BM % RPP == 0 && BN % RPP == 0 && BM <= WMAX, "window geometry");
@@ -210,12 +214,12 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     win_wload<BK, BN, NWL, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, 3 * g_ + ((s_)-3 * u_),              \
                                      u_ - g_ * kchunks, a.cout_total, a.cin, LL);                         \
   } while (0)
-#define WIN_WLOAD(s_) WIN_WLOAD_SLOT(s_, (s_) % 3)
+#define WIN_WLOAD(s_) WIN_WLOAD_SLOT(s_, (s_) % RING)
 
   // the weights do not depend on the rulebook: stages 0 and 1 are under way before anything else
   if (loader) {
     WIN_WLOAD(0);
-    WIN_WLOAD(1);
+    if (RING == 3) WIN_WLOAD(1);
   }
 
   // ---- rulebook tile -> LDS, run [lo, hi] of every kernel row, zero rows, scale/shift ------------
@@ -318,9 +322,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         for (int t = 0; t < spf; ++t, ++s) {
           if (a.diag != 2) {
             if (t == 0 && f + 1 < nfills) WIN_FILL(f + 1);
-            if (s + 2 < nstages) WIN_WLOAD(s + 2);
+            if (s + RING - 1 < nstages) WIN_WLOAD(s + RING - 1);
           }
-          if (s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
+          if (RING == 3 && s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           GGW_STAMP(lw == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // loader 0 ready for the barrier
           __builtin_amdgcn_s_barrier();
@@ -416,7 +420,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
         const char* abase = smem + ((win ? s / 3 : s) & 1) * ABUF;
         if (a.diag != 1) {
-          STAGE_MFMA(abase, wsm + (s % 3) * WBUF, 0);
+          STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // opaque-asm MFMA -> VALU read hazard
         }
         if (s + 1 < nstages) ROW_TABLE(s + 1, 0);   // static rulebook tile: next stage's rows before the barrier
@@ -518,13 +522,13 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #endif
 }
 
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT = false>
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT = false, int RING = 3>
 static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = (NWM * NWN + NWL) * 64;
-  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT>() + (size_t)9 * BM * 4 + 32 + (size_t)BN * 8;
+  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>() + (size_t)9 * BM * 4 + 32 + (size_t)BN * 8;
   static_assert(LDS <= 160 * 1024, "window kernel LDS budget");
   static const int force_gather = getenv("PN_GG_WIN_GATHER") != nullptr;
-  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT>;
+  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT, RING>;
   static bool attr_set = false;
   if (!attr_set && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
@@ -536,13 +540,23 @@ static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
   return PN_OK;
 }
 
+// Tile selection.  Template arguments: <BM, BN, NWM x NWN compute waves, NWL loader waves, BK, WMAX, TOut, UNIT, RING>.
+//   Cout <= 64   256 x Cout tiles, unit stages (a kernel row's weight tiles are <= 3 x 8 KB); 128-row tiles when
+//                the level has fewer 256-row tiles than CUs
+//   Cout <= 128  256 x 128, 4 compute waves of 64 x 128
+//   wider        128 x 256 with 8 compute waves of 64 x 64 + 8 loaders (2-6 % ahead of 4 x (64 x 128) + 4 on every
+//                256-wide shape); 64 x 128 unit-stage tiles when the level is small (a 90 x 90 map is 64 tiles of
+//                128 rows on 256 CUs: filling the chip wins 2x although every tile then streams all its weights)
+// PN_GG_WIN_CFG (tuning / tests): P = per-tap stages everywhere, D = 128 x 256 on 4 + 4 waves, T = 128 x 128 tiles
+// with a 2-deep weight ring (two workgroups per CU; within 3 % of the default on every shape measured).
 template <typename TOut>
 static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   const int N = a.cout_total;
   static const char* force = getenv("PN_GG_WIN_CFG");
   const char f = force ? force[0] : 0;
-  const bool unit = f != 'P';   // 'P': per-tap stages everywhere (tuning aid)
-  if (a.cin % 64 != 0) {   // 32 input channels
+  const bool unit = f != 'P';
+  const long long work_rows = (long long)a.rows * groups;
+  if (a.cin % 64 != 0) {   // 32 input channels: 32-channel stages
     if (N <= 32) return unit ? launch_win<256, 32, 4, 1, 2, 32, 352, TOut, true>(a, groups, stream)
                              : launch_win<256, 32, 4, 1, 2, 32, 352, TOut>(a, groups, stream);
     return unit ? launch_win<256, 64, 4, 1, 4, 32, 352, TOut, true>(a, groups, stream)
@@ -551,27 +565,15 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   if (N <= 32) return unit ? launch_win<256, 32, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                            : launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (N <= 64) {
-    if (f == 'H') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut>(a, groups, stream);   // two workgroups per CU
-    if (f == 'I') return launch_win<128, 64, 4, 1, 4, 64, 160, TOut>(a, groups, stream);   // ... with 32 x 64 wave tiles
-    if (unit && (long long)a.rows * groups <= 256 * 200)   // fewer 256-row tiles than CUs: halve them
-      return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
+    if (unit && work_rows <= 256 * 200) return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
     return unit ? launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                 : launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
-  if (N <= 128 || f == 'N') {
-    if (f == 'S') return launch_win<128, 128, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
-    if (f == 'M') return launch_win<256, 128, 4, 2, 8, 64, 320, TOut>(a, groups, stream);
-    if (f == 'U') return launch_win<128, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);   // unit stages
-    return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
-  }
-  // 8 compute waves of 64 x 64 + 8 loaders: measured 2-6 % ahead of 4 x (64 x 128) + 4 on every 256-wide shape
-  // small maps (a 90 x 90 level is 64 tiles of 128 rows on 256 CUs): 64 x 128 tiles fill the chip, and with
-  // unit stages (a kernel row's three weight tiles fit: 6 x 16 KB) a tile has 12 barriers instead of 36
-  if ((f == 'Q' || (f != 'A' && (long long)a.rows * groups <= 128 * 160)) && N % 128 == 0)
-    return launch_win<64, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);   // (160: a stride-2 run is 2*64+3 rows)
+  if (f == 'T') return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
+  if (N <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
+  if (work_rows <= 128 * 160 && N % 128 == 0)   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
+    return launch_win<64, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);
   if (f == 'D') return launch_win<128, 256, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
-  if (f == 'U') return launch_win<128, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);
-  if (f == 'M') return launch_win<256, 128, 4, 2, 8, 64, 320, TOut>(a, groups, stream);
   return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
 }
 

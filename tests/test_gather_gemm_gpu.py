@@ -147,3 +147,39 @@ def test_all_neighbours_missing_and_tiny_problems(cuda):
     count0 = torch.zeros(1, dtype=torch.int32, device=cuda)
     got = call(x, nbr, w, scale, shift, 5, count=count0)
     assert torch.isnan(got.float()).all()                    # zero active rows: nothing written, no fault
+
+
+_MODE_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import torch
+from pillarnet_lts_amd import dense_hip
+from test_gather_gemm_gpu import call, _mk, sorted_sparse_rules
+dev = torch.device("cuda:0")
+h = hashlib.sha256()
+for (cin, cout) in [(64, 64), (128, 128), (256, 256)]:
+    nbr, Ho, Wo = dense_hip.grid_rules(2, 33, 47, 1, dev)
+    x, w, scale, shift = _mk(cin, cout, 2 * 33 * 47, dev, 5)
+    h.update(call(x, nbr, w, scale, shift, 2 * Ho * Wo).cpu().view(torch.int16).numpy().tobytes())
+    nbr, M = sorted_sparse_rules(60, 500, 0.3, 7, dev)
+    x, w, scale, shift = _mk(cin, cout, M, dev, 6)
+    h.update(call(x, nbr, w, scale, shift, M, relu=False).cpu().view(torch.int16).numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_window_and_gather_modes_are_bit_identical(cuda):
+    """The window kernel's two staging modes walk (kernel row, channel chunk, kx) in the same order, so forcing
+    every tile into gather mode must not change a single output bit (fresh process per mode: the switch is read
+    once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _MODE_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    digests = {}
+    # (and a second tile shape / weight-ring depth: the accumulation order does not depend on the tiling)
+    for name, env in (("window", {}), ("gather", {"PN_GG_WIN_GATHER": "1"}), ("tiles128", {"PN_GG_WIN_CFG": "T"})):
+        out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[name] = out.stdout.strip().splitlines()[-1]
+    assert digests["window"] == digests["gather"] == digests["tiles128"], digests
