@@ -1,47 +1,23 @@
-"""det3d/models/builder.py:17-54."""
+"""Factory entry points with the reference's names (det3d/models/builder.py:17-54): one table from builder
+name to registry; a list of configs becomes an `nn.Sequential` of the built modules."""
+import functools
+
 from torch import nn
 
-from .registry import (BACKBONES, DETECTORS, HEADS, LOSSES, NECKS, POINT_HEAD, READERS, ROI_HEAD,
-                       SECOND_STAGE, build_from_cfg)
+from . import registry as _reg
 
 
 def build(cfg, registry, default_args=None):
     if isinstance(cfg, list):
-        return nn.Sequential(*[build_from_cfg(c, registry, default_args) for c in cfg])
-    return build_from_cfg(cfg, registry, default_args)
+        return nn.Sequential(*[_reg.build_from_cfg(c, registry, default_args) for c in cfg])
+    return _reg.build_from_cfg(cfg, registry, default_args)
 
 
-def build_reader(cfg):
-    return build(cfg, READERS)
-
-
-def build_backbone(cfg):
-    return build(cfg, BACKBONES)
-
-
-def build_neck(cfg):
-    return build(cfg, NECKS)
-
-
-def build_head(cfg):
-    return build(cfg, HEADS)
-
-
-def build_loss(cfg):
-    return build(cfg, LOSSES)
-
-
-def build_second_stage_module(cfg):
-    return build(cfg, SECOND_STAGE)
-
-
-def build_point_head(cfg):
-    return build(cfg, POINT_HEAD)
-
-
-def build_roi_head(cfg):
-    return build(cfg, ROI_HEAD)
+_TABLE = dict(reader=_reg.READERS, backbone=_reg.BACKBONES, neck=_reg.NECKS, head=_reg.HEADS, loss=_reg.LOSSES,
+              second_stage_module=_reg.SECOND_STAGE, point_head=_reg.POINT_HEAD, roi_head=_reg.ROI_HEAD)
+for _name, _registry in _TABLE.items():
+    globals()["build_" + _name] = functools.partial(lambda cfg, _r: build(cfg, _r), _r=_registry)
 
 
 def build_detector(cfg, train_cfg=None, test_cfg=None):
-    return build(cfg, DETECTORS, dict(train_cfg=train_cfg, test_cfg=test_cfg))
+    return build(cfg, _reg.DETECTORS, dict(train_cfg=train_cfg, test_cfg=test_cfg))
