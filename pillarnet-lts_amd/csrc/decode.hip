@@ -224,15 +224,30 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
     }
     __syncthreads();
     int filled = s_cnt;              // same value in every thread
-    for (int base = 0; base < cells && filled < DEC_LIST; base += SEL_THREADS) {
-      const int cell = base + tid;
-      const unsigned key = cell < cells ? kk[cell] : 0u;
-      int bin = key > C.key_lo ? (int)((key - C.key_lo) >> C.key_shift) : 0;
-      if (bin >= DEC_BINS) bin = DEC_BINS - 1;
-      const bool hit = key != 0u && bin == cut;
-      const unsigned long long m = __ballot(hit);
+    // eight consecutive cells per thread and iteration: the block-wide prefix of the per-thread hit counts
+    // (wave shuffles, then the 16 wave totals) ranks every hit in ascending cell order
+    for (int base = 0; base < cells && filled < DEC_LIST; base += SEL_THREADS * 8) {
+      const int c0 = base + tid * 8;
+      unsigned kv[8];
+      int mine = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cell = c0 + u;
+        unsigned key = cell < cells ? kk[cell] : 0u;
+        int bin = key > C.key_lo ? (int)((key - C.key_lo) >> C.key_shift) : 0;
+        if (bin >= DEC_BINS) bin = DEC_BINS - 1;
+        if (!(key != 0u && bin == cut)) key = 0u;
+        kv[u] = key;
+        mine += key != 0u;
+      }
       const int lane = tid & 63, wv = tid >> 6;
-      if (lane == 0) sfx[wv] = __popcll(m);
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+      }
+      if (lane == 63) sfx[wv] = incl;
       __syncthreads();
       int before = 0, total = 0;
       for (int w = 0; w < SEL_THREADS / 64; ++w) {
@@ -240,9 +255,15 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
         before += w < wv ? c : 0;
         total += c;
       }
-      const int pos = filled + before + __popcll(m & ((1ull << lane) - 1ull));
-      if (hit && pos < DEC_LIST)
-        list[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cell);
+      int pos = filled + before + incl - mine;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kv[u]) {
+          if (pos < DEC_LIST)
+            list[pos] = ((unsigned long long)kv[u] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(c0 + u));
+          ++pos;
+        }
+      }
       filled += total;
       __syncthreads();
     }
