@@ -149,10 +149,55 @@ class CenterHead(nn.Module):
             value = value[cls]
         return value
 
+    @staticmethod
+    def merge_double_flip(preds_dicts):
+        """center_head.py:233-330, the double-flip branch: every sample arrives as four views (original, y -> -y,
+        x -> -x, both); the maps are flipped back, sign-corrected and averaged -- heat map after the sigmoid, size
+        after the exp, IoU after its clamp.  Returned in the *raw* parameterisation the decode kernel reads (logit
+        of the mean probability, log of the mean size, 2 i - 1), so the fused decode needs no second code path."""
+        merged = []
+        for pd in preds_dicts:
+            n = pd["hm"].shape[0]
+            assert n % 4 == 0, n
+            v = {}
+            for k, t in pd.items():
+                t = t.float().reshape(n // 4, 4, *t.shape[1:]).clone()       # [B, 4, C, H, W]
+                t[:, 1] = torch.flip(t[:, 1], dims=[2])
+                t[:, 2] = torch.flip(t[:, 2], dims=[3])
+                t[:, 3] = torch.flip(t[:, 3], dims=[2, 3])
+                v[k] = t
+            out = {}
+            p = torch.sigmoid(v["hm"]).mean(dim=1)
+            out["hm"] = torch.log(p) - torch.log1p(-p)
+            out["dim"] = torch.log(torch.exp(v["dim"].clamp(min=-1.2, max=3.2)).mean(dim=1))
+            out["height"] = v["height"].mean(dim=1)
+            if "iou" in v:
+                out["iou"] = 2.0 * torch.clamp((v["iou"] + 1) * 0.5, min=0, max=1.0).mean(dim=1) - 1.0
+            reg = v["reg"]                                   # channels (x, y)
+            reg[:, 1, 1] = 1 - reg[:, 1, 1]
+            reg[:, 2, 0] = 1 - reg[:, 2, 0]
+            reg[:, 3] = 1 - reg[:, 3]
+            out["reg"] = reg.mean(dim=1)
+            rot = v["rot"]                                   # channels (sin, cos)
+            rot[:, 1, 1] *= -1
+            rot[:, 2, 0] *= -1
+            rot[:, 3] *= -1
+            out["rot"] = rot.mean(dim=1)
+            if "vel" in v:
+                vel = v["vel"]
+                vel[:, 1, 1] *= -1
+                vel[:, 2, 0] *= -1
+                vel[:, 3] *= -1
+                out["vel"] = vel.mean(dim=1)
+            merged.append(out)
+        return merged
+
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         if test_cfg.get("double_flip", False):
-            raise NotImplementedError("double_flip test-time augmentation is not built on the HIP path yet")
+            preds_dicts = self.merge_double_flip(preds_dicts)
+            if isinstance(example, dict) and example.get("metadata"):
+                example = dict(example, metadata=example["metadata"][::4])
         if test_cfg.get("circular_nms", False):
             raise NotImplementedError("circular_nms (CPU numba in the reference) is not built")
         nms_cfg = test_cfg["nms"]

@@ -239,6 +239,40 @@ def golden_decode(head, preds):
         arrays[f"{b}.box3d_lidar"] = d["box3d_lidar"].numpy()
         arrays[f"{b}.scores"] = d["scores"].numpy()
         arrays[f"{b}.label_preds"] = d["label_preds"].numpy()
+    # double-flip testing: four views per sample (original, y-flip, x-flip, both), merged inside predict.  The
+    # reference's branch only runs for heads WITH an IoU output (without one its `batch_iou` placeholder keeps the
+    # un-merged [B, 4, H] shape and post_processing raises), so this fixture uses an IoU head (Waymo style, 7-dim).
+    import logging
+    from det3d.models.bbox_heads.center_head import CenterHead
+    tasks = [Config(dict(stride=8, class_names=["car"]))._cfg_dict,
+             Config(dict(stride=8, class_names=["bus", "trailer"]))._cfg_dict]
+    heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "iou": (1, 2)}
+    torch.manual_seed(19)
+    head4 = CenterHead(tasks=tasks, in_channels=[24], code_weights=[1.0] * 8, common_heads=heads,
+                       logger=logging.getLogger("golden"), share_channel=16, reg_iou="GIoU", pillar_size=0.075,
+                       point_cloud_range=[-6, -4.8, -5.0, 6, 4.8, 3.0]).eval()
+    randomize_bn(head4, 6)
+    with torch.no_grad():
+        for th in head4.task_heads:
+            th.hm[-1].weight.mul_(6.0)
+        preds4 = head4((torch.randn(8, 24, 16, 20),))
+    cfg_df = Config(dict(nms=dict(use_rotate_nms=True, nms_pre_max_size=100, nms_post_max_size=20,
+                                  nms_iou_threshold=0.2), rectifier=0.5, score_threshold=0.1, double_flip=True,
+                         post_center_limit_range=[-7, -6, -10.0, 7, 6, 10.0]))._cfg_dict
+    cfg_df = set_by_task_cfg(cfg_df, head4.num_classes)
+    for t, pd in enumerate(preds4):
+        for k, v in pd.items():
+            arrays[f"df.in.{t}.{k}"] = v.numpy().copy()
+    out4 = head4.predict({"metadata": [{"token": i} for i in range(8)]},
+                         [{k: v.clone() for k, v in pd.items()} for pd in preds4], cfg_df)
+    assert len(out4) == 2
+    for b, d in enumerate(out4):
+        arrays[f"df.{b}.box3d_lidar"] = d["box3d_lidar"].numpy()
+        arrays[f"df.{b}.scores"] = d["scores"].numpy()
+        arrays[f"df.{b}.label_preds"] = d["label_preds"].numpy()
+        arrays[f"df.{b}.token"] = np.asarray(d["metadata"]["token"])
+    with open(os.path.join(HERE, "decode_df_test_cfg.json"), "w") as f:
+        json.dump(json.loads(json.dumps(cfg_df)), f, indent=1)
     save("decode.npz", **arrays)
     with open(os.path.join(HERE, "decode_test_cfg.json"), "w") as f:
         json.dump(json.loads(json.dumps(test_cfg)), f, indent=1)

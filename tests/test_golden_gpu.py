@@ -75,3 +75,25 @@ def test_predict_matches_reference_predict(cuda):
         np.testing.assert_array_equal(out[b]["label_preds"].cpu().numpy(), d[f"{b}.label_preds"])
         np.testing.assert_allclose(out[b]["scores"].cpu().numpy(), d[f"{b}.scores"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(out[b]["box3d_lidar"].cpu().numpy(), d[f"{b}.box3d_lidar"], rtol=1e-5, atol=1e-5)
+
+
+def test_predict_double_flip_matches_reference(cuda):
+    """test_cfg.double_flip: the four views of every sample are merged (maps flipped back, signs fixed, averaged
+    after sigmoid / exp / IoU clamp) before the fused decode -- against the reference's own predict on an IoU
+    head (its double-flip branch raises for heads without an IoU output)."""
+    d = np.load(os.path.join(G, "decode.npz"))
+    with open(os.path.join(G, "decode_df_test_cfg.json")) as f:
+        test_cfg = ConfigDict(json.load(f))
+    heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "iou": (1, 2)}
+    head = CenterHead(tasks=[dict(t) for t in TASKS], in_channels=[24], code_weights=[1.0] * 8, common_heads=heads,
+                      share_channel=16, reg_iou="GIoU", pillar_size=0.075,
+                      point_cloud_range=[-6, -4.8, -5.0, 6, 4.8, 3.0]).to(cuda).eval()
+    preds = [{k: torch.from_numpy(d[f"df.in.{t}.{k}"]).to(cuda) for k in list(heads) + ["hm"]} for t in range(2)]
+    out = head.predict({"metadata": [{"token": i} for i in range(8)]}, preds, test_cfg)
+    assert len(out) == 2
+    for b in range(2):
+        assert out[b]["metadata"]["token"] == int(d[f"df.{b}.token"]) == 4 * b
+        np.testing.assert_array_equal(out[b]["label_preds"].cpu().numpy(), d[f"df.{b}.label_preds"])
+        np.testing.assert_allclose(out[b]["scores"].cpu().numpy(), d[f"df.{b}.scores"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(out[b]["box3d_lidar"].cpu().numpy(), d[f"df.{b}.box3d_lidar"], rtol=2e-5, atol=2e-5)
+        assert out[b]["box3d_lidar"].shape[1] == 7
