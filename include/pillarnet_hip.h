@@ -100,7 +100,9 @@ int pn_pillarize(const pnPillarGrid* g, const float* points, int64_t n_points,
  *            sorted by score descending; cap <= 4096
  * counts_dev device int32[num_sets] valid boxes per set (clamped to cap), or NULL to
  *            use the host value count_host for every set
- * thresh_dev device fp32[num_sets] IoU thresholds or NULL -> `thresh` for all
+ * thresh_dev device fp32[num_sets] IoU thresholds or NULL -> `thresh` for all; a negative threshold -t
+ *            turns the set into circle NMS: squared centre distance <= t suppresses
+ *            (det3d/core/utils/circle_nms_jit.py:5-28)
  * post_max_dev device int32[num_sets] or NULL -> `post_max` for all
  * keep       [num_sets, keep_stride] int32: positions (into the sorted set) of the
  *            kept boxes, ascending; num_keep device int32[num_sets]
@@ -204,7 +206,9 @@ typedef struct {
   float score_threshold;   /* test_cfg.score_threshold */
   float rectifier;         /* test_cfg.rectifier: score^(1-r) * iou^r */
   int32_t use_rectify;     /* report the rectified score */
-  float nms_threshold;
+  float nms_threshold;     /* IoU threshold; a NEGATIVE value -t selects circle NMS: a kept box suppresses every
+                              lower-scored one whose squared centre distance is <= t
+                              (test_cfg.circular_nms / min_radius, det3d/core/utils/circle_nms_jit.py:5-28) */
   int32_t pre_max, post_max;
 } pnDecodeGroup;
 

@@ -198,11 +198,10 @@ class CenterHead(nn.Module):
             preds_dicts = self.merge_double_flip(preds_dicts)
             if isinstance(example, dict) and example.get("metadata"):
                 example = dict(example, metadata=example["metadata"][::4])
-        if test_cfg.get("circular_nms", False):
-            raise NotImplementedError("circular_nms (CPU numba in the reference) is not built")
         nms_cfg = test_cfg["nms"]
-        multi_class = bool(nms_cfg.get("use_multi_class_nms", False))
-        if not multi_class and not nms_cfg.get("use_rotate_nms", False):
+        circular = bool(test_cfg.get("circular_nms", False))     # center_head.py:378-386, before the other modes
+        multi_class = bool(nms_cfg.get("use_multi_class_nms", False)) and not circular
+        if not circular and not multi_class and not nms_cfg.get("use_rotate_nms", False):
             raise NotImplementedError
         dev = preds_dicts[0]["hm"].device
         if dev.type != "cuda":
@@ -239,6 +238,13 @@ class CenterHead(nn.Module):
                 g.nms_threshold = float(self._task_param(nms_cfg["nms_iou_threshold"], t, k))
                 g.pre_max = int(self._task_param(nms_cfg["nms_pre_max_size"], t, k))
                 g.post_max = int(self._task_param(nms_cfg["nms_post_max_size"], t, k))
+                if circular:
+                    # circle NMS on the raw heat-map score (`_circle_nms`, center_head.py:418-424): squared centre
+                    # distance <= min_radius[task] suppresses; the reference ranks ALL cells above the score
+                    # threshold, here the best 4096 per task
+                    g.rectifier, g.use_rectify = 0.0, 0
+                    g.nms_threshold = -float(test_cfg["min_radius"][t])
+                    g.pre_max = 4096
                 out_cap += g.post_max
                 groups.append(g)
             label_offset += self.num_classes[t]

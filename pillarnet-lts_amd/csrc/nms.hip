@@ -206,9 +206,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_mask_kernel(
     if (gr < n) {
       for (int k = 0; k < 16; ++k) {
         const int c = c0 + k, gc = cb * NMS_TILE + c;
-        if (gc < n && gc > gr && !(thr >= 0.f && circles_apart(rowg[r], colg[c]))) {
-          const int pos = atomicAdd(&pcount, 1);
-          plist[pos] = (unsigned short)((r << 6) | c);
+        if (gc < n && gc > gr) {
+          if (thr < 0.f) {   // circle NMS (circle_nms_jit.py:5-28): squared centre distance <= -thr suppresses
+            const float dx = rowg[r].cx - colg[c].cx, dy = rowg[r].cy - colg[c].cy;
+            if (dx * dx + dy * dy <= -thr) atomicOr(&lmask[r], 1ull << c);
+          } else if (!circles_apart(rowg[r], colg[c])) {
+            const int pos = atomicAdd(&pcount, 1);
+            plist[pos] = (unsigned short)((r << 6) | c);
+          }
         }
       }
     }

@@ -273,6 +273,18 @@ def golden_decode(head, preds):
         arrays[f"df.{b}.token"] = np.asarray(d["metadata"]["token"])
     with open(os.path.join(HERE, "decode_df_test_cfg.json"), "w") as f:
         json.dump(json.loads(json.dumps(cfg_df)), f, indent=1)
+    # circle NMS (numba `circle_nms`, here interpreted): on the first fixture's maps
+    cfg_c = Config(dict(nms=dict(use_rotate_nms=True, nms_pre_max_size=100, nms_post_max_size=[20, 15],
+                                 nms_iou_threshold=0.2), rectifier=0, score_threshold=0.1, double_flip=False,
+                        circular_nms=True, min_radius=[0.6, 1.5],
+                        post_center_limit_range=[-7, -6, -10.0, 7, 6, 10.0]))._cfg_dict
+    outc = head.predict({"metadata": [None, None]}, [{k: v.clone() for k, v in pd.items()} for pd in preds], cfg_c)
+    for b, d in enumerate(outc):
+        arrays[f"circle.{b}.box3d_lidar"] = d["box3d_lidar"].numpy()
+        arrays[f"circle.{b}.scores"] = d["scores"].numpy()
+        arrays[f"circle.{b}.label_preds"] = d["label_preds"].numpy()
+    with open(os.path.join(HERE, "decode_circle_test_cfg.json"), "w") as f:
+        json.dump(json.loads(json.dumps(cfg_c)), f, indent=1)
     save("decode.npz", **arrays)
     with open(os.path.join(HERE, "decode_test_cfg.json"), "w") as f:
         json.dump(json.loads(json.dumps(test_cfg)), f, indent=1)

@@ -97,3 +97,19 @@ def test_predict_double_flip_matches_reference(cuda):
         np.testing.assert_allclose(out[b]["scores"].cpu().numpy(), d[f"df.{b}.scores"], rtol=0, atol=5e-6)
         np.testing.assert_allclose(out[b]["box3d_lidar"].cpu().numpy(), d[f"df.{b}.box3d_lidar"], rtol=2e-5, atol=2e-5)
         assert out[b]["box3d_lidar"].shape[1] == 7
+
+
+def test_predict_circular_nms_matches_reference(cuda):
+    """test_cfg.circular_nms: centre-distance suppression (the reference's numba `circle_nms` on the CPU) through the
+    same mask + greedy-select kernels, selected by a negative threshold."""
+    head, g = _head(cuda)
+    d = np.load(os.path.join(G, "decode.npz"))
+    with open(os.path.join(G, "decode_circle_test_cfg.json")) as f:
+        test_cfg = ConfigDict(json.load(f))
+    preds = [{k: torch.from_numpy(g[f"out.{t}.{k}"]).to(cuda) for k in list(HEADS) + ["hm"]} for t in range(2)]
+    out = head.predict({"metadata": [None, None]}, preds, test_cfg)
+    for b in range(2):
+        np.testing.assert_array_equal(out[b]["label_preds"].cpu().numpy(), d[f"circle.{b}.label_preds"])
+        np.testing.assert_allclose(out[b]["scores"].cpu().numpy(), d[f"circle.{b}.scores"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out[b]["box3d_lidar"].cpu().numpy(), d[f"circle.{b}.box3d_lidar"], rtol=1e-5, atol=1e-5)
+    assert out[0]["scores"].shape[0] == 35          # the per-task caps 20 + 15 are both reached
