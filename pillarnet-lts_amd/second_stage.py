@@ -358,6 +358,63 @@ def sigmoid_focal_loss(logits, target, weights, alpha=0.25, gamma=2.0):
     return loss * weights
 
 
+class _Swap(nn.Module):
+    """(b, n, d) <-> (b, d, n): the parameter-free `Rearrange` steps of mlp_layers.py:89-93."""
+
+    def forward(self, x):
+        return x.transpose(1, 2)
+
+
+class MLPMixer(nn.Module):
+    """roi_heads/mlp_layers.py:24-63: token mixing over the RoI grid points, then channel mixing, both residual."""
+
+    def __init__(self, in_channels, num_patches, expansion_factor=4, expansion_factor_token=0.5):
+        super().__init__()
+        inner = int(num_patches * expansion_factor)
+        self.token_mixer = nn.Sequential(build_norm_layer(dict(type="LN"), in_channels)[1],
+                                         nn.Conv1d(num_patches, inner, kernel_size=1), nn.GELU(),
+                                         nn.Conv1d(inner, num_patches, kernel_size=1))
+        inner = int(in_channels * expansion_factor_token)
+        self.channel_mixer = nn.Sequential(build_norm_layer(dict(type="LN"), in_channels)[1],
+                                           nn.Linear(in_channels, inner), nn.GELU(), nn.Linear(inner, in_channels))
+
+    def forward(self, x):                     # [B, patches, C]
+        x = self.token_mixer(x) + x
+        return self.channel_mixer(x) + x
+
+
+class _Affine(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones((1, 1, dim)))
+        self.beta = nn.Parameter(torch.zeros((1, 1, dim)))
+
+    def forward(self, x):
+        return self.alpha * x + self.beta
+
+
+class ResMLPLayer(nn.Module):
+    """roi_heads/mlp_layers.py:66-117."""
+
+    def __init__(self, in_channels, num_patches, expansion_factor=2, layer_scale_init=1e-4):
+        super().__init__()
+        self.token_aff = _Affine(in_channels)
+        self.token_scale = nn.Parameter(layer_scale_init * torch.ones(in_channels))
+        self.token_mixer = nn.Sequential(_Swap(), nn.Linear(num_patches, num_patches), _Swap())
+        self.channel_aff = _Affine(in_channels)
+        self.channel_scale = nn.Parameter(layer_scale_init * torch.ones(in_channels))
+        self.channel_mixer = nn.Sequential(nn.Linear(in_channels, in_channels * expansion_factor), nn.GELU(),
+                                           nn.Linear(in_channels * expansion_factor, in_channels))
+        self.post_aff = _Affine(in_channels)
+
+    def forward(self, x):
+        x = self.token_aff(x)
+        x = x + self.token_scale * self.token_mixer(x)
+        x = self.channel_aff(x)
+        x = x + self.channel_scale * self.channel_mixer(x)
+        return self.post_aff(x)
+
+
 def _fc_stack(cfg_list, cin, cout, dp_ratio, conv=True):
     layers, pre = [], cin
     for k, c in enumerate(cfg_list):
@@ -378,9 +435,12 @@ class RoIMIXHead(nn.Module):
         super().__init__()
         self.model_cfg, self.test_cfg, self.num_class = model_cfg, test_cfg, num_class
         self.code_size, self.add_box_param, self.num_patches = code_size, add_box_param, num_patches
-        if mixer_type in ("MLPMixer", "ResMLP"):
-            raise NotImplementedError(f"mixer_type {mixer_type!r} is not built (the live config uses '')")
-        self.mlp_mixer = nn.Sequential()
+        if mixer_type == "MLPMixer":
+            self.mlp_mixer = MLPMixer(in_channels=in_channels, num_patches=num_patches)
+        elif mixer_type == "ResMLP":
+            self.mlp_mixer = ResMLPLayer(in_channels=in_channels, num_patches=num_patches)
+        else:
+            self.mlp_mixer = nn.Sequential()
         pre = in_channels * num_patches
         shared, fcs = [], list(model_cfg["SHARED_FC"])
         for k, c in enumerate(fcs):

@@ -101,9 +101,7 @@ def install_stubs():
               SparseSequential=torch.nn.Sequential, SparseInverseConv2d=_Any, SparseReLU=torch.nn.ReLU)
     sp.pytorch = spp
     mod("spconv.utils")
-    mod("einops")
-    mod("einops.layers")
-    mod("einops.layers.torch", Rearrange=_Any, Reduce=_Any)
+    # (einops itself is installed in this image: mlp_layers.py's Rearrange runs for real)
     mod("pyquaternion", Quaternion=object)
     mod("cv2")
     mod("shapely")
@@ -514,6 +512,18 @@ def golden_rcnn():
         for k in ("box3d_lidar", "scores", "label_preds"):
             arrays[f"det.{i}.{k}"] = d[k].numpy()
     for tag, m in (("bev", bev), ("roi", roi), ("ph", ph)):
+        arrays.update({f"sd.{tag}." + k: v for k, v in to_np(m.state_dict()).items()})
+    # the two RoI mixers (mixer_type 'MLPMixer' / 'ResMLP'; the live config uses '')
+    from det3d.models.roi_heads.mlp_layers import MLPMixer, ResMLPLayer
+    xm = torch.randn(6, 49, 16, generator=g)
+    arrays["mix.in"] = xm.numpy()
+    for tag, cls in (("mlpmixer", MLPMixer), ("resmlp", ResMLPLayer)):
+        torch.manual_seed(23)
+        m = cls(in_channels=16, num_patches=49).eval()
+        with torch.no_grad():
+            for prm in m.parameters():
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+            arrays[f"mix.{tag}.out"] = m(xm).numpy()
         arrays.update({f"sd.{tag}." + k: v for k, v in to_np(m.state_dict()).items()})
     save("rcnn.npz", **arrays)
 

@@ -205,3 +205,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PillarnetHipError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_roi_mixers_match_reference_modules():
+    """MLPMixer / ResMLPLayer (mlp_layers.py) with the reference's parameter names, against the reference modules'
+    outputs (tests/golden/rcnn.npz); pure torch, runs on the CPU."""
+    import torch
+    from pillarnet_lts_amd import second_stage
+    g = np.load(os.path.join(G, "rcnn.npz"))
+    x = torch.from_numpy(g["mix.in"])
+    for tag, cls in (("mlpmixer", second_stage.MLPMixer), ("resmlp", second_stage.ResMLPLayer)):
+        m = cls(in_channels=16, num_patches=49).eval()
+        sd = {k[len(f"sd.{tag}."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"sd.{tag}.")}
+        m.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            np.testing.assert_allclose(m(x).numpy(), g[f"mix.{tag}.out"], rtol=1e-5, atol=1e-6)
+    head = second_stage.RoIMIXHead(in_channels=16, model_cfg=P.ConfigDict(SHARED_FC=[32], CLS_FC=[32], REG_FC=[32], DP_RATIO=0.3),
+                                   mixer_type="ResMLP", num_patches=49)
+    assert "mlp_mixer.token_mixer.1.weight" in head.state_dict()
