@@ -260,9 +260,10 @@ int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows
                            long long out_rows_group_stride, pnStream stream);
 
 /* Spatial half of a 3x3 conv whose per-tap channel products z = x . [W_0 | ... | W_8] were computed
- * first (as a 1-tap GEMM): out[p, c] = bias[c] + sum_tap z[nbr[tap][p], tap*channels + c], fp32.
+ * first (as a 1-tap GEMM): out[p, c] = bias[c] + sum_tap z[nbr[tap][p], tap*channels + c], summed and
+ * stored in fp32; z is fp32 or bf16 (z_dtype = PN_DTYPE_*; strides in elements).
  * Grouped: group g uses z + g*z_group_stride, bias + g*channels, out + g*out_group_stride. */
-int pn_tap_sum(const float* z, int z_ld, long long z_group_stride, const int32_t* nbr,
+int pn_tap_sum(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
                int nbr_stride, int rows, int channels, int groups, const float* bias,
                float* out, int out_ld, long long out_group_stride, pnStream stream);
 

@@ -85,7 +85,7 @@ SIGNATURES = {
     "pn_gather_gemm_grouped": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p, ctypes.c_longlong, c_void_p]),
-    "pn_tap_sum": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+    "pn_tap_sum": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                            c_void_p, c_int, ctypes.c_longlong, c_void_p]),
     "pn_create_point_pillar_index_stack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                                    c_void_p, c_void_p]),

@@ -472,7 +472,15 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
 
 // out[p, c] = bias[c] + sum_tap z[nbr[tap][p], tap*C + c]   (fp32): the spatial half of a 3x3 conv
 // whose per-tap channel products were computed first as one 1x1 GEMM (z = x . [W_0 | ... | W_8]).
-__global__ __launch_bounds__(256) void tap_sum_kernel(const float* __restrict__ z, int z_ld,
+template <typename TZ> __device__ __forceinline__ f32x4 load_z4(const TZ* p);
+template <> __device__ __forceinline__ f32x4 load_z4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load_z4<__bf16>(const __bf16* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+template <typename TZ>
+__global__ __launch_bounds__(256) void tap_sum_kernel(const TZ* __restrict__ z, int z_ld,
                                                       const int32_t* __restrict__ nbr, int nbr_stride,
                                                       int rows, int C, const float* __restrict__ bias,
                                                       float* __restrict__ out, int out_ld,
@@ -487,13 +495,13 @@ __global__ __launch_bounds__(256) void tap_sum_kernel(const float* __restrict__ 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int src = nbr[(size_t)tap * nbr_stride + p];
-      if (src >= 0) acc += *reinterpret_cast<const f32x4*>(z + (size_t)src * z_ld + tap * C + c);
+      if (src >= 0) acc += load_z4<TZ>(z + (size_t)src * z_ld + tap * C + c);
     }
     *reinterpret_cast<f32x4*>(out + (size_t)p * out_ld + c) = acc;
   }
 }
 
-extern "C" int pn_tap_sum(const float* z, int z_ld, long long z_group_stride, const int32_t* nbr,
+extern "C" int pn_tap_sum(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
                           int nbr_stride, int rows, int channels, int groups, const float* bias,
                           float* out, int out_ld, long long out_group_stride, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -502,8 +510,12 @@ extern "C" int pn_tap_sum(const float* z, int z_ld, long long z_group_stride, co
                "pn_tap_sum: channels / strides must be multiples of 4");
   int bx = pn_div_up((long long)rows * (channels / 4), 256);
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(tap_sum_kernel, dim3(bx, groups), dim3(256), 0, stream, z, z_ld, nbr, nbr_stride, rows,
-                     channels, bias, out, out_ld, z_group_stride, out_group_stride, channels);
+  if (z_dtype == PN_DTYPE_BF16)
+    hipLaunchKernelGGL(tap_sum_kernel<__bf16>, dim3(bx, groups), dim3(256), 0, stream, (const __bf16*)z, z_ld, nbr,
+                       nbr_stride, rows, channels, bias, out, out_ld, z_group_stride, out_group_stride, channels);
+  else
+    hipLaunchKernelGGL(tap_sum_kernel<float>, dim3(bx, groups), dim3(256), 0, stream, (const float*)z, z_ld, nbr,
+                       nbr_stride, rows, channels, bias, out, out_ld, z_group_stride, out_group_stride, channels);
   PN_CHECK_LAUNCH("tap_sum_kernel");
   return PN_OK;
 }

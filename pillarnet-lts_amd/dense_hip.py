@@ -266,6 +266,9 @@ PLANS = PlanCache()
 
 import os
 _HEAD_DIRECT = bool(os.environ.get("PN_HEAD_DIRECT"))   # tuning switch, see HeadPlan.run
+# per-tap products of the output convs: fp32 (default) or bf16 (PN_HEAD_Z_BF16=1: halves the 84 MB intermediate;
+# measured 0.3 % on the frame, so the head keeps its fp32 logits)
+_HEAD_Z_FP32 = not os.environ.get("PN_HEAD_Z_BF16")
 
 
 # ---- CenterHead: shared conv, all first-layer towers as ONE conv, one small conv per task ----------
@@ -360,14 +363,17 @@ class HeadPlan:
             if fused is not None:
                 kin, npad, wz, ones, zeros, bias, k0 = fused
                 G = len(task_convs)
-                z = torch.empty((rows, G * 9 * npad), dtype=torch.float32, device=dev)
+                zdt = torch.float32 if _HEAD_Z_FP32 else torch.bfloat16
+                z = torch.empty((rows, G * 9 * npad), dtype=zdt, device=dev)
                 rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, None, 0, 1, rows,
                                               _lib.ptr(wz), 9 * npad, G, _lib.ptr(ones), _lib.ptr(zeros), 0,
-                                              _lib.ptr(z), G * 9 * npad, 9 * npad, 1, None, 0, _lib.current_stream(dev))
+                                              _lib.ptr(z), G * 9 * npad, 9 * npad, int(_HEAD_Z_FP32), None, 0,
+                                              _lib.current_stream(dev))
                 _lib.check(rc, "pn_gather_gemm_grouped")
                 maps = torch.empty((G, rows, npad), dtype=torch.float32, device=dev)
-                rc = L.pn_tap_sum(_lib.ptr(z), G * 9 * npad, 9 * npad, _lib.ptr(nbr), nbr.shape[1], rows, npad, G,
-                                  _lib.ptr(bias), _lib.ptr(maps), npad, rows * npad, _lib.current_stream(dev))
+                rc = L.pn_tap_sum(_lib.ptr(z), _lib.PN_DTYPE_F32 if _HEAD_Z_FP32 else _lib.PN_DTYPE_BF16, G * 9 * npad,
+                                  9 * npad, _lib.ptr(nbr), nbr.shape[1], rows, npad, G, _lib.ptr(bias), _lib.ptr(maps),
+                                  npad, rows * npad, _lib.current_stream(dev))
                 _lib.check(rc, "pn_tap_sum")
                 for g, (t, _k0, _kin, nout, _npad, _wt, _ones, _bias) in enumerate(task_convs):
                     out[t] = (maps[g], nout, npad, x.B, Ho, Wo)
