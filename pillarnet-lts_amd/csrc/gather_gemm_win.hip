@@ -119,7 +119,9 @@ constexpr int win_pool_bytes() {
 // 9*kchunks; a 16-MFMA stage spent more time on its barrier and first LDS reads than on its MFMAs.
 // RING: weight tiles in flight + in use on the per-tap path: 3 (two stages ahead, counted vmcnt) or 2 (one
 // ahead; the smaller pool lets two workgroups share a CU and cover each other's barriers instead).
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT, int RING>
+// NTAPS: 9 (3x3 rulebook: three kernel rows of three taps) or 1 (a plain GEMM over the rows, rulebook optional --
+// the "window" of a tile is then its own BM consecutive rows).
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT, int RING, int NTAPS>
 __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a, int force_gather) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no __amdgpu_buffer_rsrc_t to check the helpers against
   constexpr int NWC = NWM * NWN;              // compute waves; waves NWC .. NWC+NWL-1 are loaders
@@ -131,18 +133,22 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int ABUF = (WMAX + RPP) * ROWB;   // window + one piece of zero rows (row WMAX = "no neighbour")
   constexpr int WBUF = BN * ROWB;
+  static_assert(NTAPS == 9 || NTAPS == 1, "3x3 rulebooks or 1-tap GEMMs");
+  constexpr int TPG = NTAPS == 9 ? 3 : 1;     // taps per kernel row (= per window)
+  constexpr int NG = NTAPS / TPG;             // kernel rows
+  static_assert(!UNIT || NTAPS == 9, "unit stages are a 3x3 notion");
   static_assert(RING == 2 || RING == 3, "weight ring of 2 or 3");
   static_assert(!UNIT || RING == 3, "unit kernels keep the 3-deep ring for their gather-mode tiles");
   constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>();   // staging buffers; the epilogue parks the fp32 tile here
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
-  static_assert(NWM * NWN + NWL >= 3, "three waves reduce the rulebook tile");
+  static_assert(NWM * NWN + NWL >= NG, "one wave per kernel row reduces the rulebook tile");
   static_assert(WMAX % RPP == 0 && BM % RPP == 0 && BN % RPP == 0 && BM <= WMAX, "window geometry");
   static_assert((BN / RPP) % NWL == 0, "every loader wave must issue the same number of weight pieces");
   constexpr int NWP = BN / RPP / NWL;         // weight pieces per loader wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wsm = smem + 2 * ABUF;
   int* const nbr_lds = reinterpret_cast<int*>(smem + POOL);   // [9][BM]
-  int* const meta = nbr_lds + 9 * BM;                          // lo/hi per kernel row (8 ints)
+  int* const meta = nbr_lds + NTAPS * BM;                          // lo/hi per kernel row (8 ints)
   float* const sc_lds = reinterpret_cast<float*>(meta + 8);    // [BN] scale, [BN] shift
 
   {
@@ -169,18 +175,18 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int kchunks = a.cin / BK;
-  const int nstages = 9 * kchunks;             // stage s = (kernel row g, channel chunk kc, kx t), t fastest
+  const int nstages = NTAPS * kchunks;             // stage s = (kernel row g, channel chunk kc, kx t), t fastest
   const bool loader = wave >= NWC;             // wave-uniform role
   const int lw = wave - NWC;                   // loader index (pieces are dealt round-robin over NWL)
   GGW_STAMP(wave == 0, 0);
 
   // the rulebook tile and scale / shift first: their round trip (the longest latency of the prologue) runs
   // under the descriptor / lane-offset setup and the first weight DMA below
-  int nb[(9 * BM + NT - 1) / NT];
+  int nb[(NTAPS * BM + NT - 1) / NT];
 #pragma unroll
-  for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {   // all loads in flight before the first use
+  for (int j = 0; j < (NTAPS * BM + NT - 1) / NT; ++j) {   // all loads in flight before the first use
     const int q = tid + j * NT, tap = q / BM, r = q - tap * BM, m = m0 + r;
-    nb[j] = (q < 9 * BM && m < M) ? a.nbr[(size_t)tap * a.nbr_stride + m] : -1;
+    nb[j] = (q < NTAPS * BM && m < M) ? (a.nbr ? a.nbr[(size_t)tap * a.nbr_stride + m] : m) : -1;
   }
   float scv = 0.f, shv = 0.f;
   if (tid < BN && n0 + tid < a.cout_total) {
@@ -190,7 +196,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.wt, 0, (int)((size_t)9 * a.cout_total * a.cin * 2), 0x00020000);
+      (void*)a.wt, 0, (int)((size_t)NTAPS * a.cout_total * a.cin * 2), 0x00020000);
   const unsigned in_row_bytes = (unsigned)a.in_ld * 2u;
   constexpr int NPA = (WMAX / RPP + NWL - 1) / NWL;   // window pieces per loader wave
   LoaderLanes<NWP, NPA> LL;
@@ -210,8 +216,8 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   }
 #define WIN_WLOAD_SLOT(s_, slot_)                                                                         \
   do {                                                                                                    \
-    const int u_ = (s_) / 3, g_ = u_ / kchunks;                                                           \
-    win_wload<BK, BN, NWL, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, 3 * g_ + ((s_)-3 * u_),              \
+    const int u_ = (s_) / TPG, g_ = u_ / kchunks;                                                         \
+    win_wload<BK, BN, NWL, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, TPG * g_ + ((s_)-TPG * u_),          \
                                      u_ - g_ * kchunks, a.cout_total, a.cin, LL);                         \
   } while (0)
 #define WIN_WLOAD(s_) WIN_WLOAD_SLOT(s_, (s_) % RING)
@@ -219,7 +225,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   // the weights do not depend on the rulebook: stages 0 and 1 are under way before anything else
   if (loader) {
     WIN_WLOAD(0);
-    if (RING == 3) WIN_WLOAD(1);
+    if (RING == 3 && nstages > 1) WIN_WLOAD(1);
   }
 
   // ---- rulebook tile -> LDS, run [lo, hi] of every kernel row, zero rows, scale/shift ------------
@@ -228,24 +234,25 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     *reinterpret_cast<uint4*>(smem + b * ABUF + WMAX * ROWB + q * 16) = make_uint4(0, 0, 0, 0);
   }
 #pragma unroll
-  for (int j = 0; j < (9 * BM + NT - 1) / NT; ++j) {
+  for (int j = 0; j < (NTAPS * BM + NT - 1) / NT; ++j) {
     const int q = tid + j * NT;
-    if (q < 9 * BM) nbr_lds[q] = nb[j];
+    if (q < NTAPS * BM) nbr_lds[q] = nb[j];
   }
   if (tid < BN) {
     sc_lds[tid] = scv;
     sc_lds[BN + tid] = shv;
   }
+  if (tid < 6) meta[tid] = (tid & 1) ? -1 : 0x7fffffff;   // empty runs for the kernel rows nobody reduces
   static_assert(BN <= NT, "one thread per channel stages scale / shift");
   GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt drain: the weight DMA stays in flight)
-  if (wave < 3) {   // wave g reduces kernel row g: entries [3g*BM, 3(g+1)*BM) of the tile
+  if (wave < NG) {   // wave g reduces kernel row g: entries [TPG*g*BM, TPG*(g+1)*BM) of the tile
     int lo = 0x7fffffff, hi = -1;
 #pragma unroll
-    for (int j = 0; j < (3 * BM + 63) / 64; ++j) {
+    for (int j = 0; j < (TPG * BM + 63) / 64; ++j) {
       const int q = lane + j * 64;
-      if (q < 3 * BM) {
-        const int v = nbr_lds[wave * 3 * BM + q];
+      if (q < TPG * BM) {
+        const int v = nbr_lds[wave * TPG * BM + q];
         if (v >= 0) {
           lo = min(lo, v);
           hi = max(hi, v);
@@ -277,13 +284,13 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #define UNIT_SEL(gt, v0, v1, v2) ((gt) == 0 ? (v0) : ((gt) == 1 ? (v1) : (v2)))
 #define WIN_FILL(f)                                                                                        \
   do {                                                                                                     \
-    const int u_ = win ? (f) : (f) / 3, g_ = u_ / kchunks, kc_ = u_ - g_ * kchunks;                        \
-    const int tap_ = win ? 0 : 3 * g_ + ((f)-3 * u_);                                                      \
+    const int u_ = win ? (f) : (f) / TPG, g_ = u_ / kchunks, kc_ = u_ - g_ * kchunks;                      \
+    const int tap_ = win ? 0 : TPG * g_ + ((f)-TPG * u_);                                                  \
     win_fill<BK, WMAX, BM, NWL, NWP, NPA>(smem + ((f)&1) * ABUF, rs_in, lw, lane, win,                     \
                                           UNIT_SEL(g_, lo0, lo1, lo2), win ? UNIT_SEL(g_, cnt0, cnt1, cnt2) : BM, \
                                           kc_, nbr_lds + tap_ * BM, in_row_bytes, LL);                     \
   } while (0)
-  const int spf = win ? 3 : 1;                 // stages per fill
+  const int spf = win ? TPG : 1;               // stages per fill
   const int nfills = nstages / spf;
 
   f32x16 acc[TM][TN];
@@ -337,7 +344,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     int aoff[3][TM], akey[3][TM];   // window row (byte offset, swizzle key) of this lane's sites, per tap slot
 #define ROW_TABLE(s_, slot_)                                                 \
   do {                                                                       \
-    const int u_ = (s_) / 3, g_ = u_ / kchunks, tap_ = 3 * g_ + ((s_)-3 * u_); \
+    const int u_ = (s_) / TPG, g_ = u_ / kchunks, tap_ = TPG * g_ + ((s_)-TPG * u_); \
     const int lo_ = UNIT_SEL(g_, lo0, lo1, lo2);                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                         \
       const int site = wm * WTM + i * 32 + lr;                               \
@@ -418,7 +425,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       GGW_STAMP(wave == 0, 1);
       for (int s = 0; s < nstages; ++s) {
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
-        const char* abase = smem + ((win ? s / 3 : s) & 1) * ABUF;
+        const char* abase = smem + ((win ? s / TPG : s) & 1) * ABUF;
         if (a.diag != 1) {
           STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // opaque-asm MFMA -> VALU read hazard
@@ -522,13 +529,14 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #endif
 }
 
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT = false, int RING = 3>
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT = false, int RING = 3,
+          int NTAPS = 9>
 static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = (NWM * NWN + NWL) * 64;
-  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>() + (size_t)9 * BM * 4 + 32 + (size_t)BN * 8;
+  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>() + (size_t)NTAPS * BM * 4 + 32 + (size_t)BN * 8;
   static_assert(LDS <= 160 * 1024, "window kernel LDS budget");
   static const int force_gather = getenv("PN_GG_WIN_GATHER") != nullptr;
-  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT, RING>;
+  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT, RING, NTAPS>;
   static bool attr_set = false;
   if (!attr_set && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
@@ -577,8 +585,21 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
 }
 
+// 1-tap GEMMs (the head's per-tap products, the parity GEMMs of the transposed convs): the same pipeline with the
+// tile's own rows as its window.  Narrow outputs stay on the per-tap kernel.
+template <typename TOut>
+static int dispatch_win1(const GGArgs& a, int groups, hipStream_t stream) {
+  if (a.cin % 64 != 0 || a.cout_total <= 64) return -1;
+  if (a.cout_total <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut, false, 3, 1>(a, groups, stream);
+  return launch_win<128, 256, 2, 4, 8, 64, 192, TOut, false, 3, 1>(a, groups, stream);
+}
+
 int pn_gg_try_window(const GGArgs& a, int groups, bool out_fp32, hipStream_t stream) {
   static const bool off = getenv("PN_GG_NO_WIN") != nullptr;
-  if (off || a.ntaps != 9 || a.nbr == nullptr || a.in_bytes == 0 || a.diag == 3) return -1;
+  static const bool off1 = getenv("PN_GG_NO_WIN1") != nullptr;
+  if (off || a.in_bytes == 0 || a.diag == 3) return -1;
+  if (a.ntaps == 1 && !off1)
+    return out_fp32 ? dispatch_win1<float>(a, groups, stream) : dispatch_win1<__bf16>(a, groups, stream);
+  if (a.ntaps != 9 || a.nbr == nullptr) return -1;
   return out_fp32 ? dispatch_win<float>(a, groups, stream) : dispatch_win<__bf16>(a, groups, stream);
 }

@@ -183,3 +183,30 @@ def test_window_and_gather_modes_are_bit_identical(cuda):
         assert out.returncode == 0, out.stderr[-2000:]
         digests[name] = out.stdout.strip().splitlines()[-1]
     assert digests["window"] == digests["gather"] == digests["tiles128"], digests
+
+
+@pytest.mark.parametrize("cin,cout,fp32_out", [(256, 256, False), (384, 112, True), (64, 128, False), (128, 320, False)])
+def test_one_tap_gemm_identity_rulebook_and_scatter(cuda, cin, cout, fp32_out):
+    """ntaps == 1: a plain GEMM over the rows (rulebook NULL = identity, or an explicit row map), optionally
+    scattered through out_rows -- the head's per-tap products and the transposed convs' parity GEMMs."""
+    g = torch.Generator().manual_seed(cin + cout)
+    R, rows = 3000, 2900
+    x = torch.randn(R, cin, generator=g).to(cuda).bfloat16()
+    w = (torch.randn(1, cout, cin, generator=g) / cin ** 0.5).to(cuda).bfloat16()
+    scale = (torch.rand(cout, generator=g) + 0.5).to(cuda)
+    shift = (torch.randn(cout, generator=g) * 0.1).to(cuda)
+    ident = torch.arange(rows, dtype=torch.int32, device=cuda).view(1, rows)
+    want = reference(x, ident, w, scale, shift, None, True, rows)
+    tol = 2e-3 if fp32_out else 2e-2
+    out = torch.full((rows, cout), float("nan"), dtype=torch.float32 if fp32_out else torch.bfloat16, device=cuda)
+    rc = _lib.lib().pn_gather_gemm(_lib.ptr(x), cin, cin, R, None, 0, 1, None, rows, _lib.ptr(w), cout, _lib.ptr(scale),
+                                   _lib.ptr(shift), None, 0, 1, _lib.ptr(out), cout, int(fp32_out), None,
+                                   _lib.current_stream(cuda))
+    _lib.check(rc, "pn_gather_gemm")
+    assert (out.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    # explicit (shuffled) rulebook + scattered output rows
+    perm = torch.randperm(R, generator=g)[:rows].int().to(cuda).view(1, rows)
+    dest = torch.randperm(rows, generator=g).int().to(cuda)
+    got = call(x, perm, w, scale, shift, rows, fp32_out=fp32_out, out_rows=dest)
+    want = reference(x, perm, w, scale, shift, None, True, rows)
+    assert (got[dest.long()].float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
