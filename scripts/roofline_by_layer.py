@@ -10,7 +10,9 @@ for fi, s in enumerate(starts):
     e = starts[fi + 1] if fi + 1 < len(starts) else len(rows)
     k = 0
     for r in rows[s:e]:
-        if "gg_win_kernelILi128ELi256ELi2ELi4ELi8E" in r["Kernel_Name"] or "gg_win_kernel<128, 256, 2, 4, 8" in r["Kernel_Name"]:
+        n = r["Kernel_Name"]
+        if ("gg_win_kernelILi128ELi256ELi2ELi4ELi8E" in n and "ELi1EEv" not in n) or \
+           ("gg_win_kernel<128, 256, 2, 4, 8" in n and not n.split("(")[0].rstrip(">").endswith(", 1")):
             per[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
             k += 1
 for k in sorted(per):
