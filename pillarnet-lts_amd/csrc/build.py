@@ -20,6 +20,9 @@ ARCH = "gfx950"
 FLAGS = [
     "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}",
     "-ffp-contract=off",  # torch runs sub / mul / add as separately rounded kernels
+    # no packed-fp32 VALU forms (v_pk_{add,mul,fma}_f32): hipcc -O3 would otherwise emit them from
+    # ordinary float code
+    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
     "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{HERE}",
 ]
 
