@@ -114,6 +114,22 @@ int pn_nms_rotated(const float* boxes, int num_sets, int cap, const int32_t* cou
                    int32_t* keep, int32_t* num_keep, void* workspace,
                    size_t workspace_bytes, pnStream stream);
 
+/* pn_nms_rotated without the workspace argument, for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference (whose nms_gpu calls cudaMalloc / cudaFree per call,
+ * iou3d_nms.cpp:125-137).  The suppression bit matrix lives in a PN_NMS_STATIC_BYTES array inside
+ * the library's device image (one copy per GPU, held until the process ends); the call allocates
+ * and frees nothing.  Limit: pn_nms_workspace_bytes(num_sets, cap) <= PN_NMS_STATIC_BYTES
+ * (16 sets of 1024 boxes, or one set of 4096), otherwise PN_ENOSPC.  Every call on a GPU uses
+ * that GPU's one array: calls that overlap on one GPU (two streams, two threads) race; calls
+ * queued on one stream do not.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress); make one call per device before capturing a graph. */
+#define PN_NMS_STATIC_BYTES ((size_t)2 << 20)
+int pn_nms_rotated_static(const float* boxes, int num_sets, int cap, const int32_t* counts_dev,
+                          int count_host, const float* thresh_dev, float thresh,
+                          const int32_t* post_max_dev, int post_max, int keep_stride,
+                          int32_t* keep, int32_t* num_keep, pnStream stream);
+
 /* iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu / boxes_aligned_overlap_bev_gpu
  * (iou3d_nms_api.cpp:12-14, kernels iou3d_nms_kernel.cu:236-278).
  * out is [na, nb] (aligned = 0) or [na] (aligned = 1, na == nb); want_iou = 0 -> overlap area. */

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pn_nms_rotated": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_float,
                                c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
+    "pn_nms_rotated_static": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_float,
+                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pn_boxes_pairwise_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                       c_void_p]),
     "pn_spconv_subm_rules": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

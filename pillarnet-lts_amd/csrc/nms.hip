@@ -24,6 +24,7 @@
 // -ffp-contract=off: products and sums round separately, as in the reference's CPU twin
 // (iou3d_cpu.cpp) which the oracle is pinned to.
 #include "common.h"
+#include <mutex>
 
 static constexpr float IOU_EPS = 1e-8f;
 static constexpr float IN_BOX_MARGIN = 1e-2f;
@@ -340,6 +341,54 @@ extern "C" int pn_nms_rotated(const float* boxes, int num_sets, int cap, const i
                      keep_stride, keep, num_keep);
   PN_CHECK_LAUNCH("nms_select_kernel");
   return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pn_nms_rotated for callers that may not allocate: the suppression bit matrix lives in a
+// file-scope device array instead of a caller workspace.  Each GPU holds its own copy of the array
+// at its own address; the address is resolved once per device and cached.  The bit matrix needs no
+// clearing between calls: nms_mask_kernel writes every word nms_select_kernel reads.
+static constexpr size_t NMS_STATIC_BYTES = PN_NMS_STATIC_BYTES;   // 16 sets x 1024 boxes, or 1 x 4096
+static constexpr int NMS_STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char scratch[NMS_STATIC_BYTES];
+static void* g_static_mask[NMS_STATIC_MAX_DEVICES];
+static std::mutex g_static_mask_lock;
+
+static int nms_static_mask(void** out) {
+  int dev = -1;
+  PN_CHECK_HIP(hipGetDevice(&dev));
+  PN_CHECK_ARG(dev >= 0 && dev < NMS_STATIC_MAX_DEVICES, "pn_nms_rotated_static: device %d out of range", dev);
+  std::lock_guard<std::mutex> guard(g_static_mask_lock);
+  if (!g_static_mask[dev]) {
+    void* p = nullptr;
+    PN_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    PN_CHECK_ARG(p != nullptr, "pn_nms_rotated_static: no device address for the static bit matrix");
+    g_static_mask[dev] = p;
+  }
+  *out = g_static_mask[dev];
+  return PN_OK;
+}
+
+extern "C" int pn_nms_rotated_static(const float* boxes, int num_sets, int cap,
+                                     const int32_t* counts_dev, int count_host,
+                                     const float* thresh_dev, float thresh,
+                                     const int32_t* post_max_dev, int post_max, int keep_stride,
+                                     int32_t* keep, int32_t* num_keep, pnStream stream_) {
+  PN_CHECK_ARG(num_sets >= 1 && cap >= 1 && cap <= 4096,
+               "pn_nms_rotated_static: sets %d cap %d (cap <= 4096)", num_sets, cap);
+  const size_t need = pn_nms_workspace_bytes(num_sets, cap);
+  if (need > NMS_STATIC_BYTES) {
+    pn_set_error("pn_nms_rotated_static: %d sets x %d boxes need a %zu-byte bit matrix, the static "
+                 "one holds %zu bytes; use pn_nms_rotated with a caller workspace",
+                 num_sets, cap, need, NMS_STATIC_BYTES);
+    return PN_ENOSPC;
+  }
+  void* mask = nullptr;
+  const int rc = nms_static_mask(&mask);
+  if (rc != PN_OK) return rc;
+  return pn_nms_rotated(boxes, num_sets, cap, counts_dev, count_host, thresh_dev, thresh,
+                        post_max_dev, post_max, keep_stride, keep, num_keep, mask, NMS_STATIC_BYTES,
+                        stream_);
 }
 
 extern "C" int pn_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb,

@@ -1,0 +1,78 @@
+"""pn_nms_rotated_static (the entry point that allocates nothing: its suppression bit matrix is a
+static device array inside the library) against pn_nms_rotated (caller workspace), both through the
+C ABI.  Bar: keep lists and counts bit-exact, on two calls in a row -- the second with a smaller
+input, so stale words of the first call's bit matrix sit behind the second call's -- and against
+the C oracle.  Sizes beyond the static array are rejected with PN_ENOSPC."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iou3d
+from pillarnet_lts_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+IOU_TOL = 2e-5
+
+
+def _call(fn_name, boxes, counts, thr, post, cuda, with_workspace):
+    S, cap = boxes.shape[0], boxes.shape[1]
+    L = _lib.lib()
+    tb = torch.from_numpy(boxes).to(cuda)
+    tc = torch.tensor(counts, dtype=torch.int32, device=cuda)
+    tt = torch.tensor(thr, dtype=torch.float32, device=cuda)
+    tp = torch.tensor(post, dtype=torch.int32, device=cuda)
+    keep = torch.full((S, cap), -7, dtype=torch.int32, device=cuda)
+    num = torch.full((S,), -7, dtype=torch.int32, device=cuda)
+    args = [_lib.ptr(tb), S, cap, _lib.ptr(tc), 0, _lib.ptr(tt), 0.0, _lib.ptr(tp), cap, cap,
+            _lib.ptr(keep), _lib.ptr(num)]
+    if with_workspace:
+        wsb = L.pn_nms_workspace_bytes(S, cap)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+        args += [_lib.ptr(ws), wsb]
+    rc = getattr(L, fn_name)(*args, _lib.current_stream(cuda))
+    _lib.check(rc, fn_name)
+    torch.cuda.synchronize()
+    return keep.cpu().numpy(), num.cpu().numpy()
+
+
+def _compare(cuda, sets, counts, thr, post):
+    boxes = np.stack(sets)
+    k0, n0 = _call("pn_nms_rotated", boxes, counts, thr, post, cuda, True)
+    k1, n1 = _call("pn_nms_rotated_static", boxes, counts, thr, post, cuda, False)
+    np.testing.assert_array_equal(n1, n0)
+    for s in range(len(sets)):
+        np.testing.assert_array_equal(k1[s, : n1[s]], k0[s, : n0[s]])
+        want, gap = iou3d.nms(sets[s][: counts[s]], thr[s])
+        want = want[: post[s]]
+        if gap >= 10 * IOU_TOL:   # no consulted pair within libm distance of the threshold
+            assert n1[s] == len(want)
+            np.testing.assert_array_equal(k1[s, : n1[s]], want)
+
+
+def test_static_nms_matches_workspace_nms_twice(cuda):
+    # first call: 6 sets x 1000 boxes (the nuScenes frame's six tasks)
+    S, cap = 6, 1000
+    sets = [synth.nms_boxes(cap, seed=50 + s, cluster=1.5) for s in range(S)]
+    _compare(cuda, sets, [1000, 0, 1, 64, 777, 130], [0.2, 0.2, 0.55, 0.8, 0.2, 0.55],
+             [83, 83, 83, 10, 1000, 83])
+    # second call, smaller input on the same static array: 2 sets x 200 boxes
+    sets2 = [synth.nms_boxes(200, seed=90 + s, cluster=1.0) for s in range(2)]
+    _compare(cuda, sets2, [200, 65], [0.55, 0.2], [200, 83])
+    # and the first shape again
+    _compare(cuda, sets, [1000, 1000, 1000, 1000, 1000, 1000], [0.2] * 6, [83] * 6)
+
+
+def test_static_nms_rejects_sizes_beyond_the_static_array(cuda):
+    L = _lib.lib()
+    S, cap = 3, 4096                          # 3 x 4096 x 64 x 8 B = 6 MiB > 2 MiB
+    assert L.pn_nms_workspace_bytes(S, cap) > (2 << 20)
+    boxes = torch.zeros((S, cap, 7), device=cuda)
+    keep = torch.zeros((S, cap), dtype=torch.int32, device=cuda)
+    num = torch.zeros(S, dtype=torch.int32, device=cuda)
+    rc = L.pn_nms_rotated_static(_lib.ptr(boxes), S, cap, None, cap, None, 0.2, None, cap, cap,
+                                 _lib.ptr(keep), _lib.ptr(num), _lib.current_stream(cuda))
+    assert rc == -2
+    assert b"static" in L.pn_last_error()
+    # the largest single set fits exactly
+    one = synth.nms_boxes(4096, seed=7, extent=30.0, cluster=1.0)
+    _compare(cuda, [one], [4096], [0.55], [4096])
