@@ -8,3 +8,4 @@ from .registry import (BACKBONES, DETECTORS, HEADS, NECKS, READERS, Registry,  #
 from . import readers, backbones, necks, bbox_heads, detectors, second_stage, loading  # noqa: F401  (fill the registries)
 from .builder import (build_backbone, build_detector, build_head, build_neck,  # noqa: F401
                       build_reader)
+from .checkpoint import load_checkpoint, load_state_dict, resume, save_checkpoint  # noqa: F401

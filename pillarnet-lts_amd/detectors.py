@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from . import builder
 from .center_utils import set_by_task_cfg
+from .checkpoint import load_checkpoint
 from .registry import DETECTORS
 
 
@@ -38,11 +39,11 @@ class SingleStageDetector(BaseDetector):
     def init_weights(self, pretrained=None):
         if pretrained is None:
             return
-        from .checkpoint import load_checkpoint
+        # single_stage.py:31-38 swallows every error here; only the missing-file case is kept soft
         try:
             load_checkpoint(self, pretrained, strict=False)
             print("init weight from {}".format(pretrained))
-        except Exception:
+        except IOError:
             print("no pretrained model at {}".format(pretrained))
 
     def extract_feat(self, data):
