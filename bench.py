@@ -2,71 +2,204 @@
 """Headline benchmark: frames/s of nuScenes 10-sweep PillarNet-18 inference (BASELINE.json
 configs[1]) through the det3d-API detector on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # starts N ranks itself when N > 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --mode train --gpus N                    # configs[3]: data-parallel train step
 
 A step = one synthetic frame (10 sweeps x 30 000 points, resident in HBM) through
 `detector(example, return_loss=False)`: voxelize -> PFN -> sparse backbone -> neck -> CenterHead ->
 decode -> rotated NMS -> detections, batch 1 per GPU as tools/dist_test.py --speed_test does
 (dist_test.py:111,142-155).  Frames are independent, so N GPUs run N frame streams with no
-data-path collective ("weak" scaling); the timed region is bracketed by barrier + synchronize and
-the rank maximum is reported.  Prints ONE JSON line on rank 0.
+data-path collective ("weak" scaling), one process per GPU as tools/dist_test.py:86-127 is
+launched; the timed region is bracketed by barrier + synchronize and the rank maximum is reported.
+Prints ONE JSON line on rank 0.
+
+When WORLD_SIZE is not in the environment and --gpus N > 1, this process only launches: it starts
+N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), never
+touches the GPU itself and exits non-zero if any child fails.
+
+--dry-run replaces the GPU frame by a trivial CPU step over the gloo backend: it exists so that the
+launcher, rendezvous, barrier, rank-maximum and JSON contract can be tested without a GPU, and
+marks its line `"dry_run": true`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-1t", action="store_true",
+                    help="also time the whole oracle frame on ONE thread (minutes)")
     ap.add_argument("--probe", default="256x256", help="conv shape cinxcout for the roofline leg")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="gloo + CPU no-op step (launcher test)")
+    a = ap.parse_args(argv)
+    if a.steps is None:
+        a.steps = 30 if a.mode == "infer" else 5
+    if a.warmup is None:
+        a.warmup = 5 if a.mode == "infer" else 2
+    if a.dtype is None:
+        a.dtype = "bf16" if a.mode == "infer" else "fp32"   # the reference trains in fp32
+    return a
 
 
-def cpu_baseline(model, cfg):
-    """The oracle (CPU restatement of the reference forward) timed on this host: ONE frame of
-    configs[0] (1 sweep, 30k points, fp32), all host cores for the torch-CPU dense part."""
+# ---- launcher (parent process: no GPU call, no re-exec) ----------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """One child per GPU (tools/dist_test.py is started the same way by torch.distributed.launch:
+    dist_test.py:86-127).  Rank 0's stdout is this process's stdout."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(len(procs)))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()          # exact children of this process only
+        time.sleep(0.05)
+    return rc
+
+
+# ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------------
+def cpu_baseline(model, cfg, full_1t=False):
+    """The oracle (this repository's CPU restatement of the reference forward, kind "port") timed
+    on the host: ONE frame of the SAME workload as the GPU line (configs[1]: 10 sweeps x 30 000
+    points, fp32).  Also timed: the voxelize stage alone on one thread -- the reference's hard
+    voxelizer `points_to_voxel` (the "det3d CPU voxelizer" of configs[0], caps of
+    configs/nusc/voxelnet/nusc_centerpoint_pillarnet_h.py:151-158) and the dynamic pillarizer +
+    PFN + scatter-max."""
     import copy
+    import torch
     from oracle import detector_oracle as do
+    from oracle import pillar_oracle, voxelize
     from pillarnet_lts_amd import presets, synth
     from pillarnet_lts_amd.center_utils import set_by_task_cfg
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 32)   # torch-CPU conv stops scaling long before 256 threads
-    torch.set_num_threads(cores)
+    host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(host, 32)   # torch-CPU convolutions stop scaling (and then slow down) beyond ~32 threads
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     test_cfg = set_by_task_cfg(copy.deepcopy(presets.nusc_pillarnet18().test_cfg), model.bbox_head.num_classes)
-    pts = [synth.nusc_sweep(30000, seed=0)]
+    frame = synth.nusc_frame(10, 30000, seed=0)
+    rd = cfg.model.reader
+
+    def whole(threads):
+        torch.set_num_threads(threads)
+        t0 = time.time()
+        dets = do.pillarnet_forward(sd, [frame], cfg.model, test_cfg)
+        return time.time() - t0, len(dets[0]["scores"])
+
+    # voxelize stage, one thread (numpy / C are single-threaded here)
+    torch.set_num_threads(1)
     t0 = time.time()
-    dets = do.pillarnet_forward(sd, pts, cfg.model, test_cfg)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame of configs[0] (1 sweep, 30000 points, fp32, {len(dets[0]['scores'])} detections) "
-                      f"through oracle/detector_oracle.py in {dt:.1f} s"}
+    vox, coors, num = voxelize.points_to_voxel(frame, [0.075, 0.075, 0.2], rd.pc_range, 10, True, 120000)
+    t_hard = time.time() - t0
+    p = "reader.pfn_layers.shared_mlps"
+    g = lambda k: sd[k].numpy()
+    t0 = time.time()
+    r = pillar_oracle.pillarize([frame], rd.pc_range, rd.pillar_size, g(p + ".0.weight"), g(p + ".1.weight"),
+                                g(p + ".1.bias"), g(p + ".1.running_mean"), g(p + ".1.running_var"), 1e-3)
+    t_dyn = time.time() - t0
+    dt, ndet = whole(cores)
+    out = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "host_cores": host, "kind": "port",
+           "sample": f"1 frame of configs[1] (10 sweeps x 30000 points, fp32, {ndet} detections) through "
+                     f"oracle/detector_oracle.py in {dt:.1f} s on {cores} threads",
+           "voxelize_one_thread": {
+               "hard_voxelizer_s": round(t_hard, 4), "hard_voxels": int(vox.shape[0]),
+               "dynamic_pillarize_pfn_scatter_s": round(t_dyn, 4), "pillars": int(r["indices"].shape[0]),
+               "note": "points_to_voxel restatement (voxel 0.075x0.075x0.2, 10 points/voxel, 120000 voxels) and "
+                       "the dynamic reader, 300000 points, 1 thread"}}
+    if full_1t:
+        dt1, _ = whole(1)
+        out["one_thread"] = {"value": round(1.0 / dt1, 5), "unit": "frames/s", "seconds": round(dt1, 1)}
+    torch.set_num_threads(cores)
+    return out
 
 
-def main():
-    args = parse()
+# ---- rank body -----------------------------------------------------------------------------------
+def _dist_setup(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
-    if dist_on:
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    dist = None
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return world, rank, local, dist
+
+
+def _max_over_ranks(dist, seconds, dev):
+    import torch
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_dry(args):
+    import torch
+    world, rank, local, dist = _dist_setup(args)
+    x = torch.ones(1024)
+    barrier = (lambda: dist.barrier()) if dist is not None else (lambda: None)
+    for _ in range(args.warmup):
+        x = x * 1.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = x * 1.0
+    barrier()
+    elapsed = _max_over_ranks(dist, time.perf_counter() - t0, None)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec, nuScenes 10-sweep PillarNet-18 inference", "dry_run": True,
+                          "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 6),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                          "data": "none (launcher dry run on CPU, gloo)", "mode": args.mode,
+                          "config": {"workload": "dry run: no detector step executed"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_infer(args):
+    import torch
+    world, rank, local, dist = _dist_setup(args)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -76,61 +209,87 @@ def main():
     model = presets.build(cfg)
     synth.randomize_bn_(model, seed=1)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model_cpu_sd = None
+    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        model_cpu_sd = True
-        cpu = cpu_baseline(model, cfg)
+        cpu = cpu_baseline(model, cfg, args.cpu_baseline_1t)
     model.to_inference(dtype)
 
     # a few distinct frames per rank, all resident in HBM before the clock starts
-    frames = [torch.from_numpy(synth.nusc_frame(10, 30000, seed=100 * rank + i)).to(dev) for i in range(4)]
+    host_frames = [torch.from_numpy(synth.nusc_frame(10, 30000, seed=100 * rank + i)).pin_memory() for i in range(4)]
+    frames = [f.to(dev) for f in host_frames]
     examples = [{"points": [f], "metadata": [{"token": i}]} for i, f in enumerate(frames)]
 
     def barrier():
-        if dist_on:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     with torch.no_grad():
         for i in range(args.warmup):
             model(examples[i % len(examples)], return_loss=False)
-        cin, cout = (int(v) for v in args.probe.split("x"))
-        sparse_conv.EVENT_PROBE.update(shape=(cin, cout), events=[])
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             out = model(examples[i % len(examples)], return_loss=False)
         barrier()
-        t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = _max_over_ranks(dist, time.perf_counter() - t0, dev)
 
-    # roofline of the dominant hand-written kernel (sparse implicit GEMM at the probed width):
-    # algorithmic flops = 2*Cin*Cout * (active (site, offset) pairs), from the live rulebook
-    ev = sparse_conv.EVENT_PROBE["events"]
-    roof = None
-    if ev:
-        avg_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-        nbr, rows = sparse_conv.EVENT_PROBE["rules"], int(sparse_conv.EVENT_PROBE["rows"].item())
-        pairs = int((nbr[:, :rows] >= 0).sum().item())
-        flops = 2.0 * cin * cout * pairs
-        peak = 2500.0 if dtype == torch.bfloat16 else 157.3
-        ach = flops / (avg_ms * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same shape)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-                traffic = (pmc.get(f"spconv_{cin}x{cout}_window") or pmc.get(f"spconv_{cin}x{cout}", {})).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
-        roof = {"bound": "mfma", "kernel": f"gg_win_kernel<128,256,2,4,8,64,192,{args.dtype}> (window-staged gather-GEMM, sparse SubM {cin}->{cout})",
-                "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "active_pairs": pairs, "rows": rows}
-    sparse_conv.EVENT_PROBE.update(shape=None, events=[], rules=None, rows=None)
+        # ---- after the timed region: PCIe-inclusive rate, roofline and reader probes ------------
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pts = host_frames[i % len(host_frames)].to(dev, non_blocking=True)
+            model({"points": [pts], "metadata": [{"token": i}]}, return_loss=False)
+        barrier()
+        elapsed_h2d = _max_over_ranks(dist, time.perf_counter() - t0, dev)
+
+        cin, cout = (int(v) for v in args.probe.split("x"))
+        sparse_conv.EVENT_PROBE.update(shape=(cin, cout), events=[])
+        for i in range(min(args.steps, 8)):
+            model(examples[i % len(examples)], return_loss=False)
+        torch.cuda.synchronize()
+        ev = sparse_conv.EVENT_PROBE["events"]
+        roof = None
+        if ev:
+            # algorithmic flops = 2*Cin*Cout * (active (site, tap) pairs), counted on the live rulebook
+            avg_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            nbr, rows = sparse_conv.EVENT_PROBE["rules"], int(sparse_conv.EVENT_PROBE["rows"].item())
+            pairs = int((nbr[:, :rows] >= 0).sum().item())
+            flops = 2.0 * cin * cout * pairs
+            peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same shape)
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        pmc = json.load(f)
+                    traffic = (pmc.get(f"spconv_{cin}x{cout}_window") or pmc.get(f"spconv_{cin}x{cout}", {})).get("hbm_bytes_per_launch")
+                    break
+                except OSError:
+                    continue
+            roof = {"bound": "mfma", "kernel": f"gg_win_kernel<..,{args.dtype}> (window-staged gather-GEMM, sparse SubM {cin}->{cout})",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic, "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2),
+                    "active_pairs": pairs, "rows": rows}
+        sparse_conv.EVENT_PROBE.update(shape=None, events=[], rules=None, rows=None)
+
+        # reader (voxelize + PFN + scatter-max) as an HBM stage: HIP events on the launch stream
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sp = model.reader(examples[0])
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            sp = model.reader(examples[0])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        n_pts, n_pil = int(frames[0].shape[0]), int(sp.num_active_host())
+        rbytes = 20 * n_pts + 12 * n_pil + 4 * 32 * n_pil
+        hbm_stage = {"stage": "reader: pn_pillarize (cell ids, occupancy index, PFN MLP, scatter-max)",
+                     "bytes": rbytes, "us": round(us, 2), "GB_per_s": round(rbytes / us / 1e3, 1),
+                     "frac_of_8TBps": round(rbytes / us / 1e3 / 8000.0, 4), "points": n_pts, "pillars": n_pil,
+                     "note": "algorithmic bytes = 20 N + 12 M + 128 M; time is the whole call (several launches)"}
 
     if rank == 0:
         frames_total = args.steps * world
@@ -146,12 +305,97 @@ def main():
                        "weights": "random init (reference init rules), BN stats randomised",
                        "parallelism": f"{world} independent frame streams (no data-path collective)",
                        "detections_last_frame": int(out[0]["scores"].shape[0])},
+            "value_h2d_inclusive": round(frames_total / elapsed_h2d, 3),
             "roofline": roof,
-            "cpu_baseline": cpu if model_cpu_sd else None,
+            "hbm_stage": hbm_stage,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if dist_on:
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def run_train(args):
+    """configs[3]: one data-parallel training step of nuScenes PillarNet-18, batch 4 per GPU
+    (samples_per_gpu=4, configs/pillarnet/pillarnet_centerhead_nusc.py:160), fp32 as the reference
+    trains: forward with losses -> backward -> gradient all-reduce over RCCL -> clip -> one-cycle
+    AdamW step (tools/train.py -> torchie/apis/train.py:251-326, core/utils/dist_utils.py:45-57)."""
+    import torch
+    world, rank, local, dist = _dist_setup(args)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from pillarnet_lts_amd import presets, solver, synth, targets
+    torch.manual_seed(0)
+    cfg = presets.nusc_pillarnet18()
+    model = presets.build(cfg).to(dev).train()
+    per_gpu = 4
+    rng = cfg.model.reader.pc_range
+    samples = [targets.synthetic_example(synth.nusc_frame(10, 30000, seed=200 + 10 * rank + s),
+                                         cfg.model.bbox_head.tasks, rng, cfg.pillar_size, n_boxes=40,
+                                         seed=200 + 10 * rank + s, train_cfg=cfg.train_cfg) for s in range(per_gpu)]
+    ex = targets.collate(samples, dev)
+    trainer = solver.DataParallelTrainer(model, wd=0.01, total_steps=max(100, args.steps + args.warmup))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for step in range(args.warmup):
+        trainer.step(ex, step)
+    barrier()
+    t0 = time.perf_counter()
+    for step in range(args.warmup, args.warmup + args.steps):
+        loss, _ = trainer.step(ex, step)
+    barrier()
+    elapsed = _max_over_ranks(dist, time.perf_counter() - t0, dev)
+
+    # the gradient exchange alone: one flat all-reduce of the same byte count, bus bandwidth per the
+    # ring formula 2 (N-1)/N * bytes / t against one xGMI link (~153 GB/s)
+    n_param = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    allreduce = None
+    if dist is not None:
+        flat = torch.zeros(n_param, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        t = _max_over_ranks(dist, (time.perf_counter() - t0) / 10, dev)
+        bus = 2.0 * (world - 1) / world * flat.numel() * 4 / t / 1e9
+        allreduce = {"bytes": flat.numel() * 4, "ms": round(t * 1e3, 3), "bus_GB_per_s": round(bus, 1),
+                     "frac_of_xgmi_link_153GBps": round(bus / 153.0, 3)}
+    if rank == 0:
+        total = args.steps * per_gpu * world
+        print(json.dumps({
+            "metric": "samples/sec, nuScenes PillarNet-18 data-parallel training step",
+            "value": round(total / elapsed, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: PillarNet-18 nuScenes training step, batch 4 per GPU x "
+                                   "300000 points, 1440x1440 pillars, losses + backward + gradient all-reduce + "
+                                   "clip + one-cycle AdamW", "global_batch": per_gpu * world,
+                       "parallelism": f"dp{world}", "sync_bn": trainer.sync_bn, "overlap": trainer.overlap,
+                       "loss_last_step": round(float(loss), 4),
+                       "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
+            "allreduce": allreduce}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args, argv))
+    if args.dry_run:
+        run_dry(args)
+    elif args.mode == "train":
+        run_train(args)
+    else:
+        run_infer(args)
 
 
 if __name__ == "__main__":

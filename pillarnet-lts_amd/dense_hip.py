@@ -220,7 +220,7 @@ def compile_stack(seq):
             continue
         assert isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)), f"cannot compile {type(m).__name__}"
         bn, relu, j = None, False, i + 1
-        if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d):
+        if j < len(mods) and isinstance(mods[j], nn.modules.batchnorm._BatchNorm):
             assert not mods[j].training
             bn, j = mods[j], j + 1
         if j < len(mods) and isinstance(mods[j], (nn.ReLU, SparseReLU)):

@@ -73,6 +73,149 @@ def allreduce_grads(params, world_size=None):
             off += n
 
 
+class GradBuckets:
+    """Bucketed gradient all-reduce overlapped with backward (what DistributedDataParallel does for the
+    reference, det3d/torchie/apis/train.py:284-290), without the reference's second full all-reduce
+    (core/utils/dist_utils.py:51-57, idempotent on already-averaged gradients).
+
+    Parameters are packed, in reverse registration order (the order backward produces gradients), into
+    flat fp32 buckets of about `bucket_mb`; every parameter's `.grad` is a view into its bucket, so
+    nothing is copied.  A post-accumulate hook counts ready parameters; a full bucket is all-reduced
+    asynchronously as soon as all EARLIER buckets have been launched (every rank issues the same
+    sequence of collectives whatever order its gradients arrive in).  `finish()` launches what is left
+    -- buckets holding parameters that got no gradient this step, find_unused_parameters=True in the
+    reference -- waits, and divides by the world size.  xGMI is point-to-point (one ring link carries
+    the message), so buckets are few and large: 16 MiB -> 4 messages for PillarNet-18's 59 MB."""
+
+    def __init__(self, params, bucket_mb=16.0, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        limit = int(bucket_mb * (1 << 20)) // 4
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            if cur and size + p.numel() > limit:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.bucket_of = [], {}
+        for b, ps in enumerate(self.buckets):
+            dev = ps[0].device
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.bucket_of[p] = b
+                p.register_post_accumulate_grad_hook(self._on_grad)
+            self.flat.append(flat)
+        self.launched_early = 0
+        self._reset()
+
+    def _reset(self):
+        self.ready = [0] * len(self.buckets)
+        self.next = 0
+        self.handles = []
+        self.active = False
+
+    def begin(self, loss=None):
+        """Before backward: zero the buckets (gradients accumulate into the views) and arm the hooks.
+        With `loss`, parameters the autograd graph of `loss` does not reach are counted as ready at
+        once (DDP's find_unused_parameters=True, apis/train.py:289), so they do not hold their bucket
+        -- and every later one -- back until finish()."""
+        for flat in self.flat:
+            flat.zero_()
+        self._reset()
+        self.active = True
+        if loss is not None and loss.grad_fn is not None:
+            used, seen, stack = set(), set(), [loss.grad_fn]
+            while stack:
+                fn = stack.pop()
+                if fn is None or fn in seen:
+                    continue
+                seen.add(fn)
+                v = getattr(fn, "variable", None)
+                if v is not None:
+                    used.add(v)
+                stack.extend(f for f, _ in fn.next_functions)
+            for p in self.params:
+                if p not in used:
+                    self.ready[self.bucket_of[p]] += 1
+            self._launch_ready()
+
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _launch_ready(self, force=False):
+        while self.next < len(self.buckets) and (force or self.ready[self.next] == len(self.buckets[self.next])):
+            if self._distributed():
+                self.handles.append(dist.all_reduce(self.flat[self.next], group=self.group, async_op=True))
+                if not force:
+                    self.launched_early += 1
+            self.next += 1
+
+    def _on_grad(self, p):
+        if not self.active:
+            return
+        self.ready[self.bucket_of[p]] += 1
+        self._launch_ready()
+
+    def finish(self):
+        """After backward: every bucket reduced and averaged; `.grad` of every parameter is final."""
+        self._launch_ready(force=True)
+        for h in self.handles:
+            h.wait()
+        if self._distributed():
+            w = float(dist.get_world_size(self.group))
+            for flat in self.flat:
+                flat.div_(w)
+        self.active = False
+
+
+class DataParallelTrainer:
+    """One process per GPU; the step of Trainer.batch_processor_inline + DistOptimizerHook
+    (det3d/torchie/trainer/trainer.py:358-389, core/utils/dist_utils.py:45-57) with the wrapping of
+    train_detector (apis/train.py:267-311): synchronised BN (apex convert_syncbn_model there), gradient
+    buckets overlapped with backward, clip 35, one-cycle true-weight-decay Adam."""
+
+    def __init__(self, model, lr_max=1e-3, wd=0.01, total_steps=100, sync_bn=True, overlap=True,
+                 bucket_mb=16.0, grad_clip=35.0, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+        self.model = model
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.sync_bn = bool(sync_bn and world > 1)
+        if self.sync_bn:
+            from .nn_utils import convert_syncbn_model
+            convert_syncbn_model(model)
+        if world > 1:                     # DDP broadcasts rank 0's parameters and buffers at construction
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0)
+        self.overlap = bool(overlap)
+        self.buckets = GradBuckets(model.parameters(), bucket_mb) if overlap else None
+        self.optimizer = TrueWdAdam(model.parameters(), wd=wd)
+        self.schedule = OneCycle(total_steps, lr_max, moms, div_factor, pct_start)
+        self.grad_clip = grad_clip
+
+    def step(self, example, step):
+        self.optimizer.set(*self.schedule.at(step))
+        losses = self.model(example, return_loss=True)
+        loss = sum(losses["loss"])
+        if self.buckets is not None:
+            self.buckets.begin(loss)
+            loss.backward()
+            self.buckets.finish()
+        else:
+            self.optimizer.zero_grad()
+            loss.backward()
+            allreduce_grads(self.model.parameters())
+        if self.grad_clip:
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
+                                           self.grad_clip)
+        self.optimizer.step()
+        return float(loss.detach()), losses
+
+
 def train_step(model, example, optimizer, schedule=None, step=0, grad_clip=35.0):
     """forward(return_loss=True) -> sum of task losses -> backward -> all-reduce -> clip -> step
     (Trainer.batch_processor_inline + DistOptimizerHook.after_train_iter)."""

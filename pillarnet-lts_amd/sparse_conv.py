@@ -332,7 +332,7 @@ class SparseSequential(SparseModule):
             m = mods[i]
             if isinstance(m, SparseConvolution):
                 bn, relu, step = None, False, 1
-                if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d)
+                if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm)
                         and not mods[i + 1].training and not m.training):
                     bn, step = mods[i + 1], 2
                     if i + 2 < len(mods) and isinstance(mods[i + 2], (nn.ReLU, SparseReLU)):

@@ -15,6 +15,7 @@ Reference code executed here (imported from /root/reference, nothing copied):
   detectors.pillar_rcnn.PillarRCNN.post_process       -> rcnn.npz
   det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz
   roi_heads ProposalTargetLayer / RoIHeadTemplate.assign_targets + get_loss, PointHead targets + loss -> rcnn_train.npz
+  det3d.ops.point_cloud.point_cloud_ops.points_to_voxel (interpreted)  -> voxelize.npz
 
 The reference imports packages this image lacks (numba, addict, spconv, torchvision, terminaltables,
 its own un-built CUDA extensions); they are replaced by inert in-process module objects so that the
@@ -677,9 +678,38 @@ def golden_loading():
     save("loading.npz", **arrays)
 
 
+def golden_voxelize():
+    """The reference's hard voxelizer `points_to_voxel` (det3d/ops/point_cloud/point_cloud_ops.py:112-184;
+    numba.jit is a pass-through here, so its kernels run interpreted) on seeded clouds: a 2 000-point cloud on
+    the nuScenes legacy grid (0.075 m, caps from configs/nusc/voxelnet/nusc_centerpoint_pillarnet_h.py:151-158),
+    and small grids that hit both caps (max_points truncation, max_voxels drop), both index orders."""
+    from det3d.ops.point_cloud.point_cloud_ops import points_to_voxel
+    from pillarnet_lts_amd import synth
+    arrays = {}
+    cases = [
+        ("nusc", synth.nusc_sweep(2000, seed=11), [0.075, 0.075, 0.2], [-54, -54, -5.0, 54, 54, 3.0], 10, True, 120000),
+        ("caps", synth.nusc_sweep(3000, seed=12, r_max=6.0), [0.5, 0.5, 8.0], [-4, -4, -5.0, 4, 4, 3.0], 3, True, 150),
+        ("xyz", synth.nusc_sweep(1500, seed=13, r_max=6.0), [0.25, 0.5, 4.0], [-5, -4, -5.0, 5, 4, 3.0], 5, False, 400),
+    ]
+    for name, pts, vs, rng, max_points, reverse, max_voxels in cases:
+        pts[::97, 0] = rng[0]                     # exactly on the lower edge (kept) ...
+        pts[::101, 1] = rng[4]                    # ... and on the upper edge (dropped)
+        voxels, coors, num = points_to_voxel(pts, vs, rng, max_points, reverse, max_voxels)
+        arrays[f"{name}.points"] = pts
+        arrays[f"{name}.cfg"] = np.asarray(vs + rng + [max_points, int(reverse), max_voxels], np.float64)
+        arrays[f"{name}.voxels"], arrays[f"{name}.coors"], arrays[f"{name}.num"] = voxels, coors, num
+        print(name, voxels.shape, int(num.max()), int((num == max_points).sum()))
+    save("voxelize.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is required"
     install_stubs()
+    if len(sys.argv) > 1:                 # e.g. `make_golden.py golden_voxelize`: regenerate one fixture
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
+    golden_voxelize()
     golden_iou3d()
     golden_cfg()
     golden_reader()

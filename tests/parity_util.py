@@ -1,0 +1,60 @@
+"""Shared helpers of the parity tests: bounded comparison of NMS keep lists / detection sets when a
+consulted IoU sits within libm distance of the threshold (instead of skipping such cases)."""
+import numpy as np
+
+IOU_TOL = 2e-5          # device cosf / sinf / atan2f against glibc: IoU agrees to this (fp32, abs)
+
+
+def assert_keep_lists_match(got, want, boxes, thr, tol=10 * IOU_TOL):
+    """Keep lists (positions into the score-sorted `boxes`, pcdet frame) must be identical, except
+    that a pair whose oracle IoU lies within `tol` of `thr` may fall on either side.  Every position
+    in the symmetric difference must then be explained: it belongs to such a borderline pair, or it
+    overlaps (IoU > thr - tol) an earlier explained position -- a flipped decision changes what that
+    box suppresses further down the list.  Anything else is a real mismatch."""
+    got, want = np.asarray(got, np.int64), np.asarray(want, np.int64)
+    if np.array_equal(got, want):
+        return 0
+    from oracle import iou3d
+    iou = iou3d.iou_matrix(boxes, boxes)
+    n = boxes.shape[0]
+    near = np.abs(iou - np.float32(thr)) < tol
+    np.fill_diagonal(near, False)
+    borderline = set(np.flatnonzero(near.any(1)).tolist())
+    assert borderline, (f"keep lists differ ({np.setxor1d(got, want)[:10]}...) although no pair of the {n} boxes "
+                        f"has an IoU within {tol:g} of {thr}")
+    diff = sorted(np.setxor1d(got, want).tolist())
+    explained = []
+    for d in diff:
+        ok = d in borderline or any(iou[e, d] > thr - tol for e in explained if e < d)
+        assert ok, f"position {d} differs between the keep lists and no borderline pair explains it"
+        explained.append(d)
+    assert len(diff) <= 8 * len(borderline), (len(diff), len(borderline))
+    return len(diff)
+
+
+def assert_detections_match(got, want, min_gap, gap_tol=2e-4, max_flips=6, score_atol=2e-6, box_atol=1e-5):
+    """Detections of one sample (dicts of numpy arrays: box3d_lidar, scores, label_preds) from the
+    same head maps.  Exact (to the stated float tolerances) unless the oracle's NMS consulted an IoU
+    within `gap_tol` of its threshold (`min_gap`): then at most `max_flips` detections may be present
+    on one side only, and all others must still agree."""
+    gb, wb = np.asarray(got["box3d_lidar"]), np.asarray(want["box3d_lidar"])
+    gs, ws = np.asarray(got["scores"]), np.asarray(want["scores"])
+    gl, wl = np.asarray(got["label_preds"]), np.asarray(want["label_preds"])
+    if gb.shape == wb.shape and np.array_equal(gl, wl) and np.allclose(gs, ws, rtol=0, atol=score_atol) \
+            and np.allclose(gb, wb, rtol=1e-5, atol=box_atol):
+        return 0
+    assert min_gap < gap_tol, (f"detections differ ({gb.shape[0]} vs {wb.shape[0]}) and the oracle's closest IoU "
+                               f"is {min_gap:g} from its threshold: not a borderline case")
+    # match on (label, centre): every oracle detection but a few must have an identical partner
+    unmatched_w, used = 0, np.zeros(gb.shape[0], bool)
+    for i in range(wb.shape[0]):
+        ok = (gl == wl[i]) & (np.abs(gb[:, :2] - wb[i, :2]).max(1) <= box_atol) & (np.abs(gs - ws[i]) <= score_atol) & ~used
+        j = np.flatnonzero(ok)
+        if j.size:
+            used[j[0]] = True
+            np.testing.assert_allclose(gb[j[0]], wb[i], rtol=1e-5, atol=box_atol)
+        else:
+            unmatched_w += 1
+    flips = unmatched_w + int((~used).sum())
+    assert flips <= max_flips, f"{flips} detections differ; a borderline IoU explains at most {max_flips}"
+    return flips

@@ -15,6 +15,7 @@ from oracle import detector_oracle as do
 from oracle import sparse_oracle as so
 from pillarnet_lts_amd import presets, synth
 from pillarnet_lts_amd.center_utils import set_by_task_cfg
+from parity_util import assert_detections_match
 
 pytestmark = pytest.mark.gpu
 
@@ -91,14 +92,9 @@ def test_decode_and_nms_on_oracle_maps(cuda, built):
     out = model.bbox_head.predict({"metadata": [{}, {}]}, preds, model.test_cfg)
     for b in range(2):
         want = dets[b]
-        got_boxes = out[b]["box3d_lidar"].cpu().numpy()
-        if got_boxes.shape != want["box3d_lidar"].shape and want["min_gap"] < 2e-4:
-            pytest.skip("borderline IoU in the oracle NMS")
-        assert got_boxes.shape == want["box3d_lidar"].shape, (got_boxes.shape, want["box3d_lidar"].shape)
-        np.testing.assert_array_equal(out[b]["label_preds"].cpu().numpy(), want["label_preds"])
-        np.testing.assert_allclose(out[b]["scores"].cpu().numpy(), want["scores"], rtol=0, atol=2e-6)
-        np.testing.assert_allclose(got_boxes, want["box3d_lidar"], rtol=1e-5, atol=1e-5)
-        assert got_boxes.shape[0] > 20
+        got = {k: out[b][k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")}
+        assert_detections_match(got, want, want["min_gap"])
+        assert got["box3d_lidar"].shape[0] > 20
 
 
 def test_fp32_end_to_end_detections(cuda, built):
@@ -221,12 +217,9 @@ def test_waymo_fp32_maps_and_detections(cuda, built_waymo):
         preds = [{k: torch.from_numpy(v).to(cuda) for k, v in d.items()} for d in mid["preds"]]
         out = model.bbox_head.predict({"metadata": [None]}, preds, model.test_cfg)
     want = dets[0]
-    if out[0]["box3d_lidar"].shape[0] != want["box3d_lidar"].shape[0] and want["min_gap"] < 2e-4:
-        pytest.skip("borderline IoU in the oracle NMS")
     assert out[0]["box3d_lidar"].shape[1] == 7
-    np.testing.assert_array_equal(out[0]["label_preds"].cpu().numpy(), want["label_preds"])
-    np.testing.assert_allclose(out[0]["scores"].cpu().numpy(), want["scores"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(out[0]["box3d_lidar"].cpu().numpy(), want["box3d_lidar"], rtol=1e-5, atol=1e-5)
+    got = {k: out[0][k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")}
+    assert_detections_match(got, want, want["min_gap"])
     assert want["box3d_lidar"].shape[0] > 10
 
 

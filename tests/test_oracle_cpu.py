@@ -186,3 +186,32 @@ def test_loading_restatement_matches_reference():
     assert got.dtype == np.float32
     np.testing.assert_array_equal(got, g["combined"])
     assert got.shape[0] < sum(r.shape[0] for r in raws)      # the close-point filter removed something
+
+
+# ---- hard voxelizer ("det3d CPU voxelizer") ------------------------------------------------------
+@pytest.mark.parametrize("case", ["nusc", "caps", "xyz"])
+def test_hard_voxelizer_oracle_matches_reference_points_to_voxel(case):
+    """oracle/voxelize_oracle.c and its pure-Python twin against the outputs of the reference's own
+    points_to_voxel (det3d/ops/point_cloud/point_cloud_ops.py:112-184), bit-exact: voxel order,
+    max_points truncation, max_voxels drop, edge points, both coordinate orders."""
+    from oracle import voxelize
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "voxelize.npz"))
+    cfg = g[f"{case}.cfg"]
+    vs, rng = cfg[:3].tolist(), cfg[3:9].tolist()
+    max_points, reverse, max_voxels = int(cfg[9]), bool(cfg[10]), int(cfg[11])
+    pts = g[f"{case}.points"]
+    for fn in (voxelize.points_to_voxel, voxelize.points_to_voxel_py):
+        voxels, coors, num = fn(pts, vs, rng, max_points, reverse, max_voxels)
+        np.testing.assert_array_equal(coors, g[f"{case}.coors"])
+        np.testing.assert_array_equal(num, g[f"{case}.num"])
+        np.testing.assert_array_equal(voxels, g[f"{case}.voxels"])
+    assert len(num) > 100
+
+
+def test_hard_voxelizer_oracle_empty_and_out_of_range():
+    from oracle import voxelize
+    v, c, n = voxelize.points_to_voxel(np.zeros((0, 5), np.float32), [0.5, 0.5, 8], [-4, -4, -5, 4, 4, 3], 3, True, 10)
+    assert v.shape == (0, 3, 5) and c.shape == (0, 3) and n.shape == (0,)
+    far = np.full((7, 5), 100.0, np.float32)
+    v, c, n = voxelize.points_to_voxel(far, [0.5, 0.5, 8], [-4, -4, -5, 4, 4, 3], 3, True, 10)
+    assert v.shape[0] == 0
