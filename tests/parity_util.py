@@ -43,8 +43,15 @@ def assert_detections_match(got, want, min_gap, gap_tol=2e-4, max_flips=6, score
     if gb.shape == wb.shape and np.array_equal(gl, wl) and np.allclose(gs, ws, rtol=0, atol=score_atol) \
             and np.allclose(gb, wb, rtol=1e-5, atol=box_atol):
         return 0
-    assert min_gap < gap_tol, (f"detections differ ({gb.shape[0]} vs {wb.shape[0]}) and the oracle's closest IoU "
-                               f"is {min_gap:g} from its threshold: not a borderline case")
+    if min_gap >= gap_tol:
+        what = f"detections differ ({gb.shape[0]} vs {wb.shape[0]})"
+        if gb.shape == wb.shape:
+            bad = np.flatnonzero((gl != wl) | (np.abs(gs - ws) > score_atol) |
+                                 (np.abs(gb - wb) > box_atol + 1e-5 * np.abs(wb)).any(1))
+            i = int(bad[0])
+            what += (f": {bad.size} rows, first at {i}: labels {gl[i]} / {wl[i]}, scores {gs[i]!r} / {ws[i]!r}, "
+                     f"boxes {gb[i]} / {wb[i]}; max |dbox| {np.abs(gb - wb).max():g}, max |dscore| {np.abs(gs - ws).max():g}")
+        raise AssertionError(what + f"; the oracle's closest IoU is {min_gap:g} from its threshold: not a borderline case")
     # match on (label, centre): every oracle detection but a few must have an identical partner
     unmatched_w, used = 0, np.zeros(gb.shape[0], bool)
     for i in range(wb.shape[0]):

@@ -183,7 +183,7 @@ def test_full_size_train_step_batch4(cuda):
     trainer = solver.DataParallelTrainer(model, total_steps=20)
     assert trainer.sync_bn is False                  # one process: plain BN
     n_tensors = sum(1 for _ in model.parameters())
-    assert n_tensors == 570
+    assert n_tensors == 348 and len(model.state_dict()) == 570
     vals = []
     for step in range(3):
         v, losses = trainer.step(ex, step)
