@@ -16,6 +16,7 @@ Reference code executed here (imported from /root/reference, nothing copied):
   det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz
   roi_heads ProposalTargetLayer / RoIHeadTemplate.assign_targets + get_loss, PointHead targets + loss -> rcnn_train.npz
   det3d.ops.point_cloud.point_cloud_ops.points_to_voxel (interpreted)  -> voxelize.npz
+  det3d.torchie.parallel.collate.collate_kitti                         -> collate.json
 
 The reference imports packages this image lacks (numba, addict, spconv, torchvision, terminaltables,
 its own un-built CUDA extensions); they are replaced by inert in-process module objects so that the
@@ -678,6 +679,54 @@ def golden_loading():
     save("loading.npz", **arrays)
 
 
+def collate_batch():
+    """A seeded two-sample batch with every key family collate_kitti distinguishes (one sample given as a list of
+    sub-examples, as the double-flip pipeline produces)."""
+    rs = np.random.RandomState(5)
+
+    def sample(i, n_pts, n_vox):
+        return {
+            "metadata": {"token": f"tok{i}", "num_point_features": 5},
+            "points": rs.randn(n_pts, 5).astype(np.float32),
+            "voxels": rs.randn(n_vox, 3, 5).astype(np.float32),
+            "num_points": rs.randint(1, 4, n_vox).astype(np.int32),
+            "num_voxels": np.array([n_vox], np.int64),
+            "coordinates": rs.randint(0, 50, (n_vox, 3)).astype(np.int32),
+            "shape": np.array([1440, 1440, 40], np.int64),
+            "gt_boxes": [rs.randn(2 + i, 7), rs.randn(1, 7), np.zeros((0, 7))],
+            "hm": [rs.rand(1, 4, 4).astype(np.float32), rs.rand(2, 4, 4).astype(np.float32), rs.rand(2, 4, 4).astype(np.float32)],
+            "anno_box": [rs.randn(6, 10).astype(np.float32) for _ in range(3)],
+            "ind": [rs.randint(0, 16, 6).astype(np.int64) for _ in range(3)],
+            "mask": [(rs.rand(6) > 0.5).astype(np.uint8) for _ in range(3)],
+            "cat": [rs.randint(0, 2, 6).astype(np.int64) for _ in range(3)],
+            "gt_boxes_and_cls": rs.randn(6, 10).astype(np.float32),
+            "calib": {"rect": rs.randn(4, 4).astype(np.float32), "P2": rs.randn(3, 4).astype(np.float32)},
+        }
+    return [sample(0, 11, 4), [sample(1, 7, 3)]]
+
+
+def to_jsonable(v):
+    if isinstance(v, torch.Tensor):
+        return {"tensor": str(v.dtype), "shape": list(v.shape), "data": v.double().flatten().tolist()}
+    if isinstance(v, np.ndarray):
+        return {"ndarray": str(v.dtype), "shape": list(v.shape), "data": v.astype(np.float64).flatten().tolist()}
+    if isinstance(v, dict):
+        return {k: to_jsonable(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [to_jsonable(x) for x in v]
+    return v
+
+
+def golden_collate():
+    """The reference's own collate_kitti (det3d/torchie/parallel/collate.py:91-171) on collate_batch()."""
+    from det3d.torchie.parallel.collate import collate_kitti
+    out = collate_kitti(collate_batch(), samples_per_gpu=2)
+    path = os.path.join(HERE, "collate.json")
+    with open(path, "w") as f:
+        json.dump({"keys": list(out.keys()), "out": to_jsonable(dict(out))}, f)
+    print("wrote", path, os.path.getsize(path), "bytes", list(out.keys()))
+
+
 def golden_voxelize():
     """The reference's hard voxelizer `points_to_voxel` (det3d/ops/point_cloud/point_cloud_ops.py:112-184;
     numba.jit is a pass-through here, so its kernels run interpreted) on seeded clouds: a 2 000-point cloud on
@@ -710,6 +759,7 @@ if __name__ == "__main__":
             globals()[fn]()
         sys.exit(0)
     golden_voxelize()
+    golden_collate()
     golden_iou3d()
     golden_cfg()
     golden_reader()
