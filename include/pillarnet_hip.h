@@ -242,6 +242,40 @@ int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
                          int32_t* out_num, int32_t* status, void* workspace,
                          size_t workspace_bytes, pnStream stream);
 
+/* The same detection path with the regression heads evaluated only where they are read
+ * (det3d/models/bbox_heads/center_head.py:14-51 builds every head for every cell; predict,
+ * center_head.py:353-413, reads them at <= nms_pre_max_size cells per task):
+ *
+ *   pn_centerhead_select           groups[g].maps = the task's HEAT MAP only, [B, H*W, row_stride] fp32 with
+ *                                  channels == num_classes (has_vel / has_iou still describe the regression
+ *                                  layout; rectifier must be 0).  Ranks the cells (score threshold, class
+ *                                  filter, top pre_max, ties by ascending cell) and writes, per set (= group g,
+ *                                  sample b; set = g*B + b), rulebooks for the caller's gather-GEMMs, with
+ *                                  cap = pn_centerhead_select_capacity(...).  The rows of a set are the distinct
+ *                                  cells of the 3x3 neighbourhoods of its selected cells, ascending (maps of up
+ *                                  to 262 144 cells):
+ *                                    row_counts [G*B]         rows in use (<= 9*cap), device
+ *                                    nbr_tower [G*B][9][9*cap] shared-map row (b*H*W + cell) of each tap of the
+ *                                                             first-layer tower conv at that row's cell, or -1
+ *                                    nbr_out   [G*B][9][cap]  the nine tower rows of a selected cell, -1 where the
+ *                                                             neighbour lies outside the map (zero padding)
+ *   (caller)                       towers at the rows, output convs at the cap selected cells of every set ->
+ *                                  regression rows [G][B*cap][row_stride] fp32 (reg, height, dim, rot, [vel], [iou])
+ *   pn_centerhead_detect_selected  groups[g].maps = those rows (channels == 8 + 2*has_vel + has_iou), same
+ *                                  workspace: box decode, the centre-range mask, NMS, task merge -- outputs as
+ *                                  pn_centerhead_detect.  *status bit 1: a selected cell failed the range mask
+ *                                  while its set held more candidates than pre_max -- the reference would have
+ *                                  ranked another cell instead; redo the frame with pn_centerhead_detect.
+ * The workspace (pn_decode_workspace_bytes) carries the selection from the first call to the second. */
+int pn_centerhead_select_capacity(const pnDecodeGroup* groups, int num_groups);
+int pn_centerhead_select(const pnDecodeGroup* groups, int num_groups, const pnDecodeCommon* common, int box_dim,
+                         int32_t* nbr_tower, int32_t* nbr_out, int32_t* row_counts, void* workspace,
+                         size_t workspace_bytes, pnStream stream);
+int pn_centerhead_detect_selected(const pnDecodeGroup* groups, int num_groups, const pnDecodeCommon* common,
+                                  int box_dim, int out_cap, float* out_boxes, float* out_scores,
+                                  int32_t* out_labels, int32_t* out_num, int32_t* status, void* workspace,
+                                  size_t workspace_bytes, pnStream stream);
+
 /* ------------------------------------------------------------------------
  * LDS-tiled gather -> MFMA implicit GEMM, bf16 inputs / weights, fp32 accumulate:
  *   out[out_rows ? out_rows[m] : m, 0:cout] =
@@ -275,6 +309,17 @@ int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows
                            int out_group_cols, int out_fp32, const int32_t* out_rows,
                            long long out_rows_group_stride, pnStream stream);
 
+/* Grouped form whose groups also differ in rulebook and row block (the lazily evaluated CenterHead towers:
+ * one block of gathered rows per task): group g gathers through nbr + g*nbr_group_stride from
+ * in + g*in_group_stride (elements; 0: all groups gather from the same rows), uses weight + g*ntaps*cout*cin,
+ * scale/shift + g*cout, and writes out + g*out_group_stride (elements). */
+int pn_gather_gemm_blocks(const void* in, int cin, int in_ld, long long in_rows, long long in_group_stride,
+                          const int32_t* nbr, int nbr_stride, long long nbr_group_stride, int ntaps,
+                          const int32_t* counts_dev /* [groups] rows in use per group, or NULL: rows */, int rows,
+                          const void* weight, int cout, int groups, const float* scale, const float* shift,
+                          int relu, void* out, int out_ld, long long out_group_stride, int out_fp32,
+                          pnStream stream);
+
 /* Spatial half of a 3x3 conv whose per-tap channel products z = x . [W_0 | ... | W_8] were computed
  * first (as a 1-tap GEMM): out[p, c] = bias[c] + sum_tap z[nbr[tap][p], tap*channels + c], summed and
  * stored in fp32; z is fp32 or bf16 (z_dtype = PN_DTYPE_*; strides in elements).
@@ -282,6 +327,11 @@ int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows
 int pn_tap_sum(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
                int nbr_stride, int rows, int channels, int groups, const float* bias,
                float* out, int out_ld, long long out_group_stride, pnStream stream);
+
+/* pn_tap_sum with one rulebook per group (nbr + g*nbr_group_stride). */
+int pn_tap_sum_blocks(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
+                      int nbr_stride, long long nbr_group_stride, int rows, int channels, int groups,
+                      const float* bias, float* out, int out_ld, long long out_group_stride, pnStream stream);
 
 /* ------------------------------------------------------------------------
  * Unfused / training-path operators with the reference's pybind contracts

@@ -81,6 +81,15 @@ SIGNATURES = {
     "pn_centerhead_detect": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int,
                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "pn_centerhead_select_capacity": (c_int, [POINTER(pnDecodeGroup), c_int]),
+    "pn_centerhead_select": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_centerhead_detect_selected": (c_int, [POINTER(pnDecodeGroup), c_int, POINTER(pnDecodeCommon), c_int,
+                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_size_t, c_void_p]),
+    "pn_gather_gemm_blocks": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_int,
+                                      ctypes.c_longlong, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                      c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "pn_gather_gemm": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                c_void_p, c_void_p]),
@@ -89,6 +98,8 @@ SIGNATURES = {
                                        c_void_p, ctypes.c_longlong, c_void_p]),
     "pn_tap_sum": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                            c_void_p, c_int, ctypes.c_longlong, c_void_p]),
+    "pn_tap_sum_blocks": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, ctypes.c_longlong, c_int, c_int,
+                                  c_int, c_void_p, c_void_p, c_int, ctypes.c_longlong, c_void_p]),
     "pn_create_point_pillar_index_stack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                                    c_void_p, c_void_p]),
     "pn_create_pillar_indices": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -192,6 +192,131 @@ class CenterHead(nn.Module):
             merged.append(out)
         return merged
 
+    # ---- lazy regression heads (MI355X inference path) ---------------------------------------------------
+    def lazy_plan(self, test_cfg):
+        """The LazyHeadPlan of this head, or None when the dense path must run: training, fp32 / MIOpen
+        backends, a rectified score (needs the IoU map everywhere), double flip (averages whole maps),
+        circle NMS (ranks 4096 cells), or towers the plan does not cover."""
+        import os
+        if self.training or not getattr(self, "_dense_hip", False) or os.environ.get("PN_HEAD_DENSE"):
+            return None
+        if test_cfg.get("double_flip", False) or test_cfg.get("circular_nms", False):
+            return None
+        nms_cfg = test_cfg["nms"]
+        multi = bool(nms_cfg.get("use_multi_class_nms", False))
+        if not multi and not nms_cfg.get("use_rotate_nms", False):
+            return None
+        for t in range(len(self.task_heads)):
+            for k in (range(self.num_classes[t]) if multi else [None]):
+                if float(self._task_param(test_cfg["rectifier"], t, k)) != 0.0:
+                    return None
+        from . import dense_hip
+        plan = dense_hip.LAZY_PLANS.get(self, dense_hip.LazyHeadPlan)
+        return plan if plan.ok else None
+
+    LAZY_MAX_CELLS = 262144     # pn_centerhead_select keeps a bit per map cell in LDS
+
+    @torch.no_grad()
+    def predict_lazy(self, example, x, test_cfg, plan, **kwargs):
+        """forward + predict in one: heat maps densely, cells ranked, regression heads at the ranked cells
+        only.  Same outputs as `predict(example, self(x), test_cfg)`; falls back to exactly that when the
+        library reports that the centre-range mask would have changed the ranking (status bit 1)."""
+        from . import dense_hip
+        if any(f.shape[2] * f.shape[3] > self.LAZY_MAX_CELLS for f in x):
+            return self.predict(example, self(x), test_cfg, **kwargs)
+        feats = [dense_hip.Rows.from_nchw(f) for f in x]
+        dense = plan.run_hm(feats)
+        nms_cfg = test_cfg["nms"]
+        multi_class = bool(nms_cfg.get("use_multi_class_nms", False))
+        dev = x[0].device
+        B = x[0].shape[0]
+        has_vel = int("vel" in self.task_heads[0].heads)
+        has_iou = int("iou" in self.task_heads[0].heads)
+        groups, owner = [], []            # owner[g] = (level, task index inside the level)
+        label_offset, out_cap = 0, 0
+        for t in range(len(self.task_heads)):
+            lvl = self.task_idx[t]
+            xs, hm = dense[lvl]
+            p = plan.levels[lvl]
+            gi = t - p["tasks"][0]
+            for k in (range(self.num_classes[t]) if multi_class else [None]):
+                g = _lib.pnDecodeGroup()
+                g.maps = hm[gi].data_ptr()
+                g.height, g.width, g.channels, g.num_classes = xs.H, xs.W, self.num_classes[t], self.num_classes[t]
+                g.row_stride = p["npad_h"]
+                g.has_vel, g.has_iou = has_vel, has_iou
+                g.class_filter = -1 if k is None else k
+                g.label_offset = label_offset
+                g.stride = self.task_strides[t]
+                g.score_threshold = float(test_cfg["score_threshold"])
+                g.rectifier, g.use_rectify = 0.0, 0
+                g.nms_threshold = float(self._task_param(nms_cfg["nms_iou_threshold"], t, k))
+                g.pre_max = int(self._task_param(nms_cfg["nms_pre_max_size"], t, k))
+                g.post_max = int(self._task_param(nms_cfg["nms_post_max_size"], t, k))
+                out_cap += g.post_max
+                groups.append(g)
+                owner.append((lvl, gi))
+            label_offset += self.num_classes[t]
+        Gd = len(groups)
+        G = (_lib.pnDecodeGroup * Gd)(*groups)
+        common = _lib.pnDecodeCommon()
+        common.batch = B
+        common.pillar_size = float(np.float32(self.pillar_size))
+        common.x_min = float(np.float32(self.point_cloud_range[0]))
+        common.y_min = float(np.float32(self.point_cloud_range[1]))
+        rng = list(test_cfg.get("post_center_limit_range", []))
+        common.has_range = int(len(rng) > 0)
+        for i, v in enumerate(rng[:6]):
+            common.range[i] = float(np.float32(v))
+        L = _lib.lib()
+        nd = self.box_n_dim
+        cap = L.pn_centerhead_select_capacity(G, Gd)
+        wsb = L.pn_decode_workspace_bytes(G, Gd, B, nd)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        # one block of rows per set (set = group * B + sample)
+        nbr_tower = torch.empty((Gd * B, 9, 9 * cap), dtype=torch.int32, device=dev)
+        nbr_out = torch.empty((Gd * B, 9, cap), dtype=torch.int32, device=dev)
+        row_counts = torch.empty(Gd * B, dtype=torch.int32, device=dev)
+        st = _lib.current_stream(dev)
+        rc = L.pn_centerhead_select(G, Gd, ctypes.byref(common), nd, _lib.ptr(nbr_tower), _lib.ptr(nbr_out),
+                                    _lib.ptr(row_counts), _lib.ptr(ws), wsb, st)
+        _lib.check(rc, "pn_centerhead_select")
+        # regression rows, level by level (the decode groups of a level are consecutive)
+        keep_alive = []
+        g0 = 0
+        while g0 < Gd:
+            lvl = owner[g0][0]
+            g1 = g0
+            while g1 < Gd and owner[g1][0] == lvl:
+                g1 += 1
+            set_task = [owner[g][1] for g in range(g0, g1) for _ in range(B)]
+            reg = plan.run_reg(lvl, dense[lvl][0], set_task, nbr_tower[g0 * B:g1 * B], nbr_out[g0 * B:g1 * B],
+                               row_counts[g0 * B:g1 * B], cap)
+            keep_alive.append(reg)
+            p = plan.levels[lvl]
+            for g in range(g0, g1):
+                G[g].maps = reg[(g - g0) * B].data_ptr()      # [B, cap, npad_r] of this group
+                G[g].channels, G[g].row_stride = p["nout_r"], p["npad_r"]
+            g0 = g1
+        boxes = torch.empty((B, out_cap, nd), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, out_cap), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, out_cap), dtype=torch.int32, device=dev)
+        num = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        rc = L.pn_centerhead_detect_selected(G, Gd, ctypes.byref(common), nd, out_cap, _lib.ptr(boxes), _lib.ptr(scores),
+                                             _lib.ptr(labels), _lib.ptr(num), ctypes.c_void_p(num.data_ptr() + 4 * B),
+                                             _lib.ptr(ws), wsb, st)
+        _lib.check(rc, "pn_centerhead_detect_selected")
+        counts = num.cpu().tolist()       # the frame's single device->host sync
+        if counts[B] & 2:                 # the range mask removed ranked cells of an over-full set: dense redo
+            return self.predict(example, self(x), test_cfg, **kwargs)
+        if counts[B] & 1:
+            self.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+        metas = example.get("metadata", None) if isinstance(example, dict) else None
+        if not metas:
+            metas = [None] * B
+        return [{"box3d_lidar": boxes[b, :counts[b]], "scores": scores[b, :counts[b]],
+                 "label_preds": labels[b, :counts[b]].long(), "metadata": metas[b]} for b in range(B)]
+
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         if test_cfg.get("double_flip", False):

@@ -37,6 +37,9 @@ void pn_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// capi.hip: memset as a kernel (safe to capture into a HIP graph)
+int pn_fill_async(void* ptr, int byte, size_t bytes, hipStream_t stream);
+
 static inline size_t pn_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int pn_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
     a.shift += g * a.g_ss;
     a.out = reinterpret_cast<char*>(a.out) + g * a.g_out * (long long)sizeof(TOut);
     if (a.out_rows) a.out_rows += g * a.g_rows;
+    if (a.nbr) a.nbr += g * a.g_nbr;
+    if (a.count) a.count += g * a.g_count;
   }
   int M = a.count ? *a.count : a.rows;
   if (M > a.rows) M = a.rows;
@@ -428,7 +430,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = (const __bf16*)residual; a.res_ld = res_ld; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
-  a.g_in = a.g_wt = a.g_ss = a.g_out = a.g_rows = 0;
+  a.g_in = a.g_wt = a.g_ss = a.g_out = a.g_rows = a.g_nbr = a.g_count = 0;
   { const char* d = getenv("PN_GG_DIAG"); a.diag = d ? atoi(d) : 0; }
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   {
@@ -441,12 +443,44 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
 // `groups` independent problems that share rows / rulebook and differ by a channel offset of the
 // input (group g reads in + g*in_group_cols), their own [ntaps, cout, cin] weights and scale/shift,
 // and write out + g*out_group_cols: the per-task convs of CenterHead in one launch.
+static int gather_gemm_grouped_impl(const void* in, int cin, int in_ld, long long in_rows, long long in_group_stride,
+                                    const int32_t* nbr, int nbr_stride, long long nbr_group_stride, int ntaps,
+                                    const int32_t* count_dev, int rows, const void* weight, int cout, int groups, const float* scale,
+                                    const float* shift, int relu, void* out, int out_ld,
+                                    long long out_group_stride, int out_fp32, const int32_t* out_rows,
+                                    long long out_rows_group_stride, pnStream stream_);
+
 extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long long in_rows, int in_group_cols,
                                       const int32_t* nbr, int nbr_stride, int ntaps, int rows,
                                       const void* weight, int cout, int groups, const float* scale,
                                       const float* shift, int relu, void* out, int out_ld,
                                       int out_group_cols, int out_fp32, const int32_t* out_rows,
                                       long long out_rows_group_stride, pnStream stream_) {
+  return gather_gemm_grouped_impl(in, cin, in_ld, in_rows, in_group_cols, nbr, nbr_stride, 0, ntaps, nullptr, rows, weight,
+                                  cout, groups, scale, shift, relu, out, out_ld, out_group_cols, out_fp32, out_rows,
+                                  out_rows_group_stride, stream_);
+}
+
+// Grouped form whose groups also differ in their rulebook and row block: group g reads rows through
+// nbr + g*nbr_group_stride from in + g*in_group_stride (elements; 0 = every group gathers from the same
+// rows) and writes out + g*out_group_stride (elements); counts_dev[g] (optional, device) = rows in use.
+extern "C" int pn_gather_gemm_blocks(const void* in, int cin, int in_ld, long long in_rows, long long in_group_stride,
+                                     const int32_t* nbr, int nbr_stride, long long nbr_group_stride, int ntaps,
+                                     const int32_t* counts_dev, int rows, const void* weight, int cout, int groups, const float* scale,
+                                     const float* shift, int relu, void* out, int out_ld,
+                                     long long out_group_stride, int out_fp32, pnStream stream_) {
+  PN_CHECK_ARG(in_group_stride % 8 == 0 && out_group_stride % 4 == 0, "pn_gather_gemm_blocks: group strides not aligned");
+  return gather_gemm_grouped_impl(in, cin, in_ld, in_rows, in_group_stride, nbr, nbr_stride, nbr_group_stride, ntaps,
+                                  counts_dev, rows, weight, cout, groups, scale, shift, relu, out, out_ld, out_group_stride,
+                                  out_fp32, nullptr, 0, stream_);
+}
+
+static int gather_gemm_grouped_impl(const void* in, int cin, int in_ld, long long in_rows, long long in_group_cols,
+                                    const int32_t* nbr, int nbr_stride, long long nbr_group_stride, int ntaps,
+                                    const int32_t* count_dev, int rows, const void* weight, int cout, int groups, const float* scale,
+                                    const float* shift, int relu, void* out, int out_ld,
+                                    long long out_group_cols, int out_fp32, const int32_t* out_rows,
+                                    long long out_rows_group_stride, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(in && weight && scale && shift && out && groups >= 1 && rows >= 1,
                "pn_gather_gemm_grouped: bad argument");
@@ -456,12 +490,14 @@ extern "C" int pn_gather_gemm_grouped(const void* in, int cin, int in_ld, long l
                "pn_gather_gemm_grouped: channel counts / strides not aligned");
   GGArgs a;
   a.in = (const __bf16*)in; a.in_ld = in_ld; a.in_bytes = gg_in_bytes(in_rows, in_ld); a.nbr = nbr;
-  a.nbr_stride = nbr_stride; a.count = nullptr;
+  a.nbr_stride = nbr_stride; a.count = count_dev;
   a.rows = rows; a.wt = (const __bf16*)weight; a.cin = cin; a.cout_total = cout; a.ntaps = ntaps;
   a.scale = scale; a.shift = shift; a.residual = nullptr; a.res_ld = 0; a.relu = relu;
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
   a.g_in = in_group_cols; a.g_wt = (long long)ntaps * cout * cin; a.g_ss = cout; a.g_out = out_group_cols;
   a.g_rows = out_rows_group_stride;
+  a.g_nbr = nbr_group_stride;
+  a.g_count = count_dev ? 1 : 0;
   a.diag = 0;
   {
     const int rc = pn_gg_try_window(a, groups, out_fp32 != 0, stream);
@@ -484,9 +520,10 @@ __global__ __launch_bounds__(256) void tap_sum_kernel(const TZ* __restrict__ z, 
                                                       const int32_t* __restrict__ nbr, int nbr_stride,
                                                       int rows, int C, const float* __restrict__ bias,
                                                       float* __restrict__ out, int out_ld,
-                                                      long long g_z, long long g_out, int g_bias) {
+                                                      long long g_z, long long g_out, int g_bias,
+                                                      long long g_nbr) {
   const int g = blockIdx.y;
-  z += g * g_z; out += g * g_out; bias += g * g_bias;
+  z += g * g_z; out += g * g_out; bias += g * g_bias; nbr += g * g_nbr;
   const int c4 = C / 4;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)rows * c4;
        t += (long long)gridDim.x * 256) {
@@ -501,9 +538,29 @@ __global__ __launch_bounds__(256) void tap_sum_kernel(const TZ* __restrict__ z, 
   }
 }
 
+static int tap_sum_impl(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
+                        int nbr_stride, long long nbr_group_stride, int rows, int channels, int groups,
+                        const float* bias, float* out, int out_ld, long long out_group_stride, pnStream stream_);
+
 extern "C" int pn_tap_sum(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
                           int nbr_stride, int rows, int channels, int groups, const float* bias,
                           float* out, int out_ld, long long out_group_stride, pnStream stream_) {
+  return tap_sum_impl(z, z_dtype, z_ld, z_group_stride, nbr, nbr_stride, 0, rows, channels, groups, bias, out, out_ld,
+                      out_group_stride, stream_);
+}
+
+// pn_tap_sum with one rulebook per group (nbr + g*nbr_group_stride)
+extern "C" int pn_tap_sum_blocks(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
+                                 int nbr_stride, long long nbr_group_stride, int rows, int channels, int groups,
+                                 const float* bias, float* out, int out_ld, long long out_group_stride,
+                                 pnStream stream_) {
+  return tap_sum_impl(z, z_dtype, z_ld, z_group_stride, nbr, nbr_stride, nbr_group_stride, rows, channels, groups,
+                      bias, out, out_ld, out_group_stride, stream_);
+}
+
+static int tap_sum_impl(const void* z, int z_dtype, int z_ld, long long z_group_stride, const int32_t* nbr,
+                        int nbr_stride, long long nbr_group_stride, int rows, int channels, int groups,
+                        const float* bias, float* out, int out_ld, long long out_group_stride, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(z && nbr && bias && out && rows >= 1 && groups >= 1, "pn_tap_sum: null argument");
   PN_CHECK_ARG(channels % 4 == 0 && z_ld % 4 == 0 && out_ld % 4 == 0 && z_ld >= 9 * channels,
@@ -512,10 +569,12 @@ extern "C" int pn_tap_sum(const void* z, int z_dtype, int z_ld, long long z_grou
   if (bx > 2048) bx = 2048;
   if (z_dtype == PN_DTYPE_BF16)
     hipLaunchKernelGGL(tap_sum_kernel<__bf16>, dim3(bx, groups), dim3(256), 0, stream, (const __bf16*)z, z_ld, nbr,
-                       nbr_stride, rows, channels, bias, out, out_ld, z_group_stride, out_group_stride, channels);
+                       nbr_stride, rows, channels, bias, out, out_ld, z_group_stride, out_group_stride, channels,
+                       nbr_group_stride);
   else
     hipLaunchKernelGGL(tap_sum_kernel<float>, dim3(bx, groups), dim3(256), 0, stream, (const float*)z, z_ld, nbr,
-                       nbr_stride, rows, channels, bias, out, out_ld, z_group_stride, out_group_stride, channels);
+                       nbr_stride, rows, channels, bias, out, out_ld, z_group_stride, out_group_stride, channels,
+                       nbr_group_stride);
   PN_CHECK_LAUNCH("tap_sum_kernel");
   return PN_OK;
 }

@@ -159,6 +159,8 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     a.shift += g * a.g_ss;
     a.out = reinterpret_cast<char*>(a.out) + g * a.g_out * (long long)sizeof(TOut);
     if (a.out_rows) a.out_rows += g * a.g_rows;
+    if (a.nbr) a.nbr += g * a.g_nbr;
+    if (a.count) a.count += g * a.g_count;
   }
   int M = a.count ? *a.count : a.rows;
   if (M > a.rows) M = a.rows;

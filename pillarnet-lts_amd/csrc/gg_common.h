@@ -44,7 +44,7 @@ struct GGArgs {
   int out_ld;
   const int32_t* out_rows; // optional scatter: output row of site m (NULL: m)
   // grouped launch (blockIdx.z = group g): element offsets added per group
-  long long g_in, g_wt, g_ss, g_out, g_rows;
+  long long g_in, g_wt, g_ss, g_out, g_rows, g_nbr, g_count;
   int diag;                // 1: skip LDS reads + MFMAs (staging-rate probe), 2: skip staging (math-rate probe)
 };
 

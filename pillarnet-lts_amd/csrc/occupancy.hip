@@ -228,7 +228,7 @@ extern "C" int pn_occupancy_from_indices(const int32_t* indices, const int32_t* 
     return PN_ENOSPC;
   }
   const pnScanGeom sg = pn_scan_geom(cells);
-  PN_CHECK_HIP(hipMemsetAsync(occ_bits, 0, (size_t)sg.words * 8, stream));
+  { const int rc_ = pn_fill_async(occ_bits, 0, (size_t)sg.words * 8, stream); if (rc_ != PN_OK) return rc_; }
   int blocks = pn_div_up(cap, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(occ_mark_rows_kernel, dim3(blocks), dim3(256), 0, stream, indices, count_dev, cap, batch, H,

@@ -197,7 +197,7 @@ extern "C" int pn_pillarize(const pnPillarGrid* g, const float* points, int64_t 
     bo.off[b] = batch_offsets_host[b <= g->batch ? b : g->batch];
 
   const int64_t row_cap = n_points < cells ? n_points : cells;
-  PN_CHECK_HIP(hipMemsetAsync(occ_bytes, 0, (size_t)cells, stream));
+  { const int rc_ = pn_fill_async(occ_bytes, 0, (size_t)cells, stream); if (rc_ != PN_OK) return rc_; }
   const int n = (int)n_points;
   const int pt_blocks = n > 0 ? (pn_div_up(n, PZ_THREADS) < 2048 ? pn_div_up(n, PZ_THREADS) : 2048) : 0;
 

@@ -368,7 +368,7 @@ extern "C" int pn_sparse_to_dense(int dtype, const void* feats, const int32_t* i
     return PN_OK;
   }
   if (out_ld == C) {
-    PN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)batch * H * W * C * esz, stream));
+    { const int rc_ = pn_fill_async(out, 0, (size_t)batch * H * W * C * esz, stream); if (rc_ != PN_OK) return rc_; }
   } else {
     PN_CHECK_HIP(hipMemset2DAsync(out, (size_t)out_ld * esz, 0, (size_t)C * esz, (size_t)batch * H * W, stream));
   }

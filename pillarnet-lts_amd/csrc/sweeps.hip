@@ -123,7 +123,7 @@ extern "C" int pn_merge_sweeps(const float* raw, int raw_dim, int use_dim, const
   }
   const int total = M.start[n_sweeps];
   if (total == 0) {
-    PN_CHECK_HIP(hipMemsetAsync(out_count, 0, 4, stream));
+    { const int rc_ = pn_fill_async(out_count, 0, 4, stream); if (rc_ != PN_OK) return rc_; }
     return PN_OK;
   }
   PN_CHECK_ARG(raw && transform && has_transform && time_lag && filter_close && out && workspace,

@@ -177,7 +177,7 @@ extern "C" int pn_scatter_max(const int32_t* index, const float* src, int L, int
     return PN_ENOSPC;
   }
   unsigned long long* packed = (unsigned long long*)workspace;
-  PN_CHECK_HIP(hipMemsetAsync(packed, 0, (size_t)M * C * 8, stream));
+  { const int rc_ = pn_fill_async(packed, 0, (size_t)M * C * 8, stream); if (rc_ != PN_OK) return rc_; }
   if (L > 0) {
     PN_CHECK_ARG(index && src, "pn_scatter_max: null input");
     LAUNCH(scatter_max_pack_kernel, (long long)L * C, (long long)L * C, C, index, src, packed);
@@ -199,7 +199,7 @@ extern "C" int pn_spconv_invert_rules(const int32_t* nbr, int nbr_stride, const 
                                       int out_cap, int32_t* inv, int inv_stride, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(nbr && out_count_dev && inv && out_cap >= 1 && inv_stride >= 1, "pn_spconv_invert_rules: bad argument");
-  PN_CHECK_HIP(hipMemsetAsync(inv, 0xFF, (size_t)9 * inv_stride * 4, stream));
+  { const int rc_ = pn_fill_async(inv, 0xFF, (size_t)9 * inv_stride * 4, stream); if (rc_ != PN_OK) return rc_; }
   LAUNCH(invert_rules_kernel, 9ll * out_cap, nbr, nbr_stride, out_count_dev, out_cap, inv, inv_stride);
   return PN_OK;
 }

@@ -262,6 +262,7 @@ class PlanCache:
 
 
 PLANS = PlanCache()
+LAZY_PLANS = PlanCache()      # CenterHead -> LazyHeadPlan (PLANS holds the dense HeadPlan of the same module)
 
 
 import os
@@ -384,3 +385,151 @@ class HeadPlan:
                         in_ld=cols)
                 out[t] = (m, nout, npad, x.B, Ho, Wo)
         return [out[t] for t in sorted(out)]
+
+
+# ---- CenterHead with the regression heads evaluated only at the cells predict() reads ------------------
+class LazyHeadPlan:
+    """Dense part: shared conv, the heat-map towers of every task as ONE conv, the heat-map output convs
+    (per-tap products + tap sum, exactly as HeadPlan does them).  Sparse part, after the cells have been
+    ranked on the heat map alone: the regression towers at the 3x3 neighbourhoods of the selected cells
+    (<= nms_pre_max_size per task) and the regression output convs at the selected cells, as two grouped
+    gather-GEMMs + one tap sum over compact row blocks.  Every value is produced by the same kernels, in
+    the same summation order, as the dense plan produces it for that cell.
+
+    Reference semantics: det3d/models/bbox_heads/center_head.py:14-51 (SepHead), :116-127 (forward),
+    :353-413 (post_processing reads the regression maps only at the ranked cells)."""
+
+    def __init__(self, head):
+        dev = next(head.parameters()).device
+        self.ok, self.why = True, ""
+        self.share = [compile_stack(sc) for sc in head.share_convs]
+        self.levels = {}
+        order = [n for n in _ORDER if n != "hm"]
+        per_level = {}
+        for t, th in enumerate(head.task_heads):
+            per_level.setdefault(head.task_idx[t], []).append((t, th))
+        for lvl, items in per_level.items():
+            tasks = [t for t, _ in items]
+            if tasks != list(range(tasks[0], tasks[0] + len(tasks))):
+                self.ok, self.why = False, "tasks of one feature level are not consecutive"
+                return
+            hm_steps, reg = [], []
+            for t, th in items:
+                names = [n for n in order if n in th.heads]
+                for n in names + ["hm"]:
+                    if len(getattr(th, n)) != 4:
+                        self.ok, self.why = False, "towers are not (conv, bn, relu, conv)"
+                        return
+                hm_fc = th.hm
+                hm_steps.append((ConvStep(hm_fc[0], hm_fc[1], True), hm_fc[3]))
+                steps = [(ConvStep(getattr(th, n)[0], getattr(th, n)[1], True), getattr(th, n)[3]) for n in names]
+                reg.append(steps)
+            tw = hm_steps[0][0].cout
+            kin_r = sum(s.cout for s, _ in reg[0])
+            nout_r = sum(o.out_channels for _, o in reg[0])
+            npad_r = (nout_r + 3) // 4 * 4
+            npad_h = (max(o.out_channels for _, o in hm_steps) + 3) // 4 * 4
+            if any(s.cout != tw for s, _ in hm_steps) or \
+                    any(sum(s.cout for s, _ in r) != kin_r or sum(o.out_channels for _, o in r) != nout_r for r in reg):
+                self.ok, self.why = False, "tasks differ in tower / output widths"
+                return
+            G = len(items)
+            with torch.no_grad():
+                w_hm = torch.cat([s.w for s, _ in hm_steps], dim=1).contiguous()              # [9, G*tw, cin]
+                sc_hm = torch.cat([s.scale for s, _ in hm_steps]).contiguous()
+                sh_hm = torch.cat([s.shift for s, _ in hm_steps]).contiguous()
+                wz_hm = torch.zeros((G, 9, npad_h, tw), dtype=torch.float32, device=dev)
+                b_hm = torch.zeros((G, npad_h), dtype=torch.float32, device=dev)
+                for g, (_, o) in enumerate(hm_steps):
+                    wz_hm[g, :, :o.out_channels] = o.weight.detach().float().permute(2, 3, 0, 1).reshape(9, o.out_channels, tw)
+                    b_hm[g, :o.out_channels] = o.bias.detach().float()
+                wz_hm = wz_hm.reshape(G, 1, 9 * npad_h, tw).to(torch.bfloat16).contiguous()
+                w_reg = torch.stack([torch.cat([s.w for s, _ in r], dim=1) for r in reg]).contiguous()   # [G, 9, kin_r, cin]
+                sc_reg = torch.stack([torch.cat([s.scale for s, _ in r]) for r in reg]).contiguous()
+                sh_reg = torch.stack([torch.cat([s.shift for s, _ in r]) for r in reg]).contiguous()
+                wz_reg = torch.zeros((G, 9, npad_r, kin_r), dtype=torch.float32, device=dev)
+                b_reg = torch.zeros((G, npad_r), dtype=torch.float32, device=dev)
+                for g, r in enumerate(reg):
+                    row = col = 0
+                    for s_, o in r:
+                        wz_reg[g, :, row:row + o.out_channels, col:col + s_.cout] = \
+                            o.weight.detach().float().permute(2, 3, 0, 1).reshape(9, o.out_channels, s_.cout)
+                        b_reg[g, row:row + o.out_channels] = o.bias.detach().float()
+                        row += o.out_channels
+                        col += s_.cout
+                wz_reg = wz_reg.reshape(G, 1, 9 * npad_r, kin_r).to(torch.bfloat16).contiguous()
+            self.levels[lvl] = dict(tasks=tasks, G=G, cin=hm_steps[0][0].cin, tw=tw, npad_h=npad_h, kin_r=kin_r,
+                                    nout_r=nout_r, npad_r=npad_r, w_hm=w_hm, sc_hm=sc_hm, sh_hm=sh_hm, wz_hm=wz_hm,
+                                    b_hm=b_hm.contiguous(), w_reg=w_reg, sc_reg=sc_reg, sh_reg=sh_reg, wz_reg=wz_reg,
+                                    b_reg=b_reg.contiguous(),
+                                    ones_h=torch.ones(G * 9 * npad_h, device=dev), zeros_h=torch.zeros(G * 9 * npad_h, device=dev),
+                                    ones_r=torch.ones(9 * npad_r, device=dev), zeros_r=torch.zeros(9 * npad_r, device=dev))
+
+    def run_hm(self, feats):
+        """-> per level: (shared Rows, hm maps fp32 [G, rows, npad_h])."""
+        L = _lib.lib()
+        out = {}
+        for lvl, p in self.levels.items():
+            x = run_stack(self.share[lvl], feats[lvl])
+            nbr, Ho, Wo = grid_rules(x.B, x.H, x.W, 1, x.t.device)
+            rows, dev, G = x.B * Ho * Wo, x.t.device, p["G"]
+            tow = torch.empty((rows, G * p["tw"]), dtype=torch.bfloat16, device=dev)
+            _launch(x.t, p["cin"], nbr, 9, rows, p["w_hm"], p["sc_hm"], p["sh_hm"], True, tow, G * p["tw"], in_ld=x.ld)
+            nz = 9 * p["npad_h"]
+            z = torch.empty((rows, G * nz), dtype=torch.float32, device=dev)
+            rc = L.pn_gather_gemm_grouped(_lib.ptr(tow), p["tw"], G * p["tw"], rows, p["tw"], None, 0, 1, rows,
+                                          _lib.ptr(p["wz_hm"]), nz, G, _lib.ptr(p["ones_h"]), _lib.ptr(p["zeros_h"]), 0,
+                                          _lib.ptr(z), G * nz, nz, 1, None, 0, _lib.current_stream(dev))
+            _lib.check(rc, "pn_gather_gemm_grouped")
+            hm = torch.empty((G, rows, p["npad_h"]), dtype=torch.float32, device=dev)
+            rc = L.pn_tap_sum(_lib.ptr(z), _lib.PN_DTYPE_F32, G * nz, nz, _lib.ptr(nbr), nbr.shape[1], rows, p["npad_h"],
+                              G, _lib.ptr(p["b_hm"]), _lib.ptr(hm), p["npad_h"], rows * p["npad_h"],
+                              _lib.current_stream(dev))
+            _lib.check(rc, "pn_tap_sum")
+            out[lvl] = (x, hm)
+        return out
+
+    def _per_set(self, lvl, set_task, dev):
+        """Weights / scale / shift / bias replicated per set (a GEMM group is one set = task [x class] x sample);
+        cached per replication pattern."""
+        p = self.levels[lvl]
+        key = ("sets", tuple(set_task))
+        hit = p.get(key)
+        if hit is None:
+            n = len(set_task)
+            if list(set_task) == list(range(p["G"])):
+                hit = (p["w_reg"], p["sc_reg"], p["sh_reg"], p["wz_reg"], p["b_reg"])
+            else:
+                idx = torch.tensor(list(set_task), device=dev)
+                hit = tuple(p[k][idx].contiguous() for k in ("w_reg", "sc_reg", "sh_reg", "wz_reg", "b_reg"))
+            hit = hit + (p["ones_r"].repeat(n).contiguous(), p["zeros_r"].repeat(n).contiguous())
+            p[key] = hit
+        return hit
+
+    def run_reg(self, lvl, x, set_task, nbr_tower, nbr_out, row_counts, cap):
+        """Regression rows of one level's sets.  set_task[j]: index (within the level) of the task set j belongs
+        to; nbr_tower [Ns, 9, 9*cap], nbr_out [Ns, 9, cap], row_counts [Ns] are that level's slices of what
+        pn_centerhead_select wrote.  -> fp32 [Ns, cap, npad_r]."""
+        L = _lib.lib()
+        p = self.levels[lvl]
+        dev = x.t.device
+        Ns, R = len(set_task), 9 * cap
+        w_reg, sc, sh, wz, b, ones, zeros = self._per_set(lvl, set_task, dev)
+        kin, npad = p["kin_r"], p["npad_r"]
+        st = _lib.current_stream(dev)
+        tow = torch.empty((Ns, R, kin), dtype=torch.bfloat16, device=dev)
+        rc = L.pn_gather_gemm_blocks(_lib.ptr(x.t), p["cin"], x.ld, x.t.shape[0], 0, _lib.ptr(nbr_tower), R, 9 * R, 9,
+                                     _lib.ptr(row_counts), R, _lib.ptr(w_reg), kin, Ns, _lib.ptr(sc), _lib.ptr(sh), 1,
+                                     _lib.ptr(tow), kin, R * kin, 0, st)
+        _lib.check(rc, "pn_gather_gemm_blocks (towers)")
+        nz = 9 * npad
+        z = torch.empty((Ns, R, nz), dtype=torch.float32, device=dev)
+        rc = L.pn_gather_gemm_blocks(_lib.ptr(tow), kin, kin, R, R * kin, None, 0, 0, 1, _lib.ptr(row_counts), R,
+                                     _lib.ptr(wz), nz, Ns, _lib.ptr(ones), _lib.ptr(zeros), 0, _lib.ptr(z), nz, R * nz, 1,
+                                     st)
+        _lib.check(rc, "pn_gather_gemm_blocks (per-tap products)")
+        reg = torch.empty((Ns, cap, npad), dtype=torch.float32, device=dev)
+        rc = L.pn_tap_sum_blocks(_lib.ptr(z), _lib.PN_DTYPE_F32, nz, R * nz, _lib.ptr(nbr_out), cap, 9 * cap, cap, npad,
+                                 Ns, _lib.ptr(b), _lib.ptr(reg), npad, cap * npad, st)
+        _lib.check(rc, "pn_tap_sum_blocks")
+        return reg

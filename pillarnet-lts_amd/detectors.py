@@ -105,6 +105,11 @@ class PillarNet(SingleStageDetector):
     def forward(self, example, return_loss=True, **kwargs):
         data = dict(points=example["points"], batch_size=len(example["metadata"]))
         bev_features, _ = self.extract_feat(data)
+        if not return_loss and not kwargs:
+            # inference on the HIP dense path: regression heads only at the cells predict() ranks
+            plan = self.bbox_head.lazy_plan(self.test_cfg) if bev_features[0].dtype == torch.bfloat16 else None
+            if plan is not None:
+                return self.bbox_head.predict_lazy(example, bev_features, self.test_cfg, plan)
         preds = self.bbox_head(bev_features)
         if return_loss:
             return self.bbox_head.loss(example, preds, self.train_cfg)

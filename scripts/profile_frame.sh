@@ -7,6 +7,7 @@ OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || exit 1
 python3 scripts/summarize_rocprof.py $OUT 6 > gpurun_out/${TAG}_frame_kernels.txt
+python3 scripts/summarize_rocprof.py $OUT 6 grid > gpurun_out/${TAG}_frame_kernels_by_grid.txt
 cp $(find $OUT -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 cat $OUT/bench.json
 find $OUT -name "*.csv" -size +1M -delete

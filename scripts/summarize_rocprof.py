@@ -14,8 +14,12 @@ starts = starts[skip:]
 rows = rows[starts[0]:]
 frames = len(starts)
 agg = collections.OrderedDict()
+by_grid = len(sys.argv) > 3 and sys.argv[3] == "grid"    # split every kernel by its grid size (one line per layer shape)
 for r in rows:
-    a = agg.setdefault(r["Kernel_Name"], [0, 0, r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"]])
+    name = r["Kernel_Name"]
+    if by_grid:
+        name = f'{name[:60]} grid {r.get("Grid_Size_X", r.get("Grid_Size", "?"))}x{r.get("Grid_Size_Y", "")}x{r.get("Grid_Size_Z", "")}'
+    a = agg.setdefault(name, [0, 0, r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"]])
     a[0] += 1
     a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 busy = sum(a[1] for a in agg.values())
