@@ -27,6 +27,10 @@ FLAGS = [
 ]
 
 
+# tuning builds: extra hipcc flags (e.g. -DPN_DECODE_STAMPS) from the environment
+FLAGS += os.environ.get("PN_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def _sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
 

@@ -120,6 +120,69 @@ __global__ __launch_bounds__(256) void decode_score_kernel(DecodeGroups G, Decod
   }
 }
 
+// Descending bitonic sort of E * SEL_THREADS entries held E per thread in registers (thread t owns entries
+// t*E .. t*E+E-1).  A compare-exchange with a partner in the same thread is a register swap, in the same
+// wavefront a shuffle; only partners in another wavefront (distance >= 64*E) go through LDS and a barrier --
+// 10 of the 55-91 passes.  The plain LDS version below spent ~1000 cycles per pass on its barrier.
+template <int E>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long* a) {
+  const int t = threadIdx.x;
+  unsigned long long v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) v[r] = a[t * E + r];
+  constexpr int P = E * SEL_THREADS;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64 * E) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) a[t * E + r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int e = t * E + r;
+          const unsigned long long y = a[e ^ j];
+          const bool keep_max = ((e & k) == 0) == ((e & j) == 0);
+          v[r] = keep_max ? (v[r] > y ? v[r] : y) : (v[r] < y ? v[r] : y);
+        }
+      } else if (j >= E) {
+        const int lane_xor = j / E;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int e = t * E + r;
+          const unsigned lo = __shfl_xor((unsigned)(v[r] & 0xFFFFFFFFull), lane_xor);
+          const unsigned hi = __shfl_xor((unsigned)(v[r] >> 32), lane_xor);
+          const unsigned long long y = ((unsigned long long)hi << 32) | lo;
+          const bool keep_max = ((e & k) == 0) == ((e & j) == 0);
+          v[r] = keep_max ? (v[r] > y ? v[r] : y) : (v[r] < y ? v[r] : y);
+        }
+      } else {
+        // same thread: j is 1, 2 or 4 here; every register index below is a compile-time constant (a run-time
+        // index would move v[] to scratch memory)
+#pragma unroll
+        for (int J = 1; J < E; J <<= 1) {
+          if (j == J) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+              if ((r & J) == 0) {
+                const bool desc = (((t * E + r) & k) == 0);
+                const unsigned long long x = v[r], y = v[r | J];
+                const unsigned long long mx = x > y ? x : y, mn = x > y ? y : x;
+                v[r] = desc ? mx : mn;
+                v[r | J] = desc ? mn : mx;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) a[t * E + r] = v[r];
+  __syncthreads();
+}
+
 __device__ __forceinline__ void bitonic_sort_desc(unsigned long long* a, int n /*pow2*/) {
   for (int k = 2; k <= n; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -136,6 +199,17 @@ __device__ __forceinline__ void bitonic_sort_desc(unsigned long long* a, int n /
   }
 }
 
+// -DPN_DECODE_STAMPS (tuning builds only): s_memtime at the phase boundaries of set 0's workgroup
+#ifdef PN_DECODE_STAMPS
+__device__ unsigned long long dec_stamps[16];
+extern "C" int pn_decode_debug_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dec_stamps), (size_t)(n > 16 ? 16 : n) * 8);
+}
+#define DEC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) dec_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEC_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
     DecodeGroups G, DecodeCommonDev C, const unsigned* __restrict__ keys,
     const unsigned* __restrict__ hist, int pre_cap, int box_dim, float* __restrict__ nms_boxes,
@@ -150,6 +224,7 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
   const DecodeSetDev& S = G.g[group];
   const int cells = S.H * S.W, tid = threadIdx.x;
   int pre_max = S.pre_max < pre_cap ? S.pre_max : pre_cap;
+  DEC_STAMP(0);
 
   // ---- cut-off bin: the highest bin t such that #keys in bins >= t reaches pre_max -----------
   constexpr int BPT = DEC_BINS / SEL_THREADS;  // bins per thread, thread 0 owns the TOP bins
@@ -182,6 +257,7 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
   }
   __syncthreads();
   const int cut = s_cut;  // 0 when the set holds fewer than pre_max candidates
+  DEC_STAMP(1);
   // candidates are the keys >= klo; those >= khi lie above the cut-off range (fewer than pre_max of them)
   unsigned long long klo = cut == 0 ? 1ull : (unsigned long long)C.key_lo + ((unsigned long long)cut << C.key_shift);
   unsigned long long khi = cut == DEC_BINS - 1 ? (1ull << 32)
@@ -243,6 +319,7 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
     __syncthreads();   // `list` is reused below
   }
 
+  DEC_STAMP(2);
   // ---- collect ----------------------------------------------------------------------------------
   // keys are fetched 8 at a time per thread (independent loads in flight) -- a load-test-append loop
   // serialises one L2 round trip per cell and was most of this kernel's time
@@ -274,6 +351,7 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
   }
   __syncthreads();
   int n = s_cnt;
+  DEC_STAMP(3);
   if (n > DEC_LIST) {
     // More cells inside the cut-off range than the list holds (maps full of equal scores): report it,
     // and collect again by a fixed rule -- every key above the cut-off range, then the range's cells in
@@ -334,11 +412,21 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
     }
     n = filled < DEC_LIST ? filled : DEC_LIST;
   }
-  int p2 = 1;
+  DEC_STAMP(4);
+  int p2 = SEL_THREADS;              // one entry per thread at least; the padding (0) sorts to the end
   while (p2 < n) p2 <<= 1;
   for (int i = n + tid; i < p2; i += SEL_THREADS) list[i] = 0ull;
   __syncthreads();
-  bitonic_sort_desc(list, p2);
+  static_assert(DEC_LIST == 8 * SEL_THREADS, "sort dispatch covers 1, 2, 4 and 8 entries per thread");
+  if (p2 == SEL_THREADS) bitonic_sort_regs<1>(list);
+  else if (p2 == 2 * SEL_THREADS) bitonic_sort_regs<2>(list);
+  else if (p2 == 4 * SEL_THREADS) bitonic_sort_regs<4>(list);
+  else bitonic_sort_regs<8>(list);
+  DEC_STAMP(5);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { DEC_STAMP(7); }
+#ifdef PN_DECODE_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) { dec_stamps[8] = (unsigned long long)n; dec_stamps[9] = (unsigned long long)p2; dec_stamps[10] = (unsigned long long)s_sub + 1; }
+#endif
   const int m = n < pre_max ? n : pre_max;
   if (tid == 0) {
     counts[set] = m;
