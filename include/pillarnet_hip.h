@@ -208,7 +208,7 @@ int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, 
  * channel order  reg(2) height(1) dim(3) rot(2: sin, cos) [vel(2)] [iou(1)] hm(num_classes).
  * Output, per sample b: the kept boxes of its groups concatenated in group order --
  * out_boxes [B, out_cap, box_dim] (x,y,z,dx,dy,dz,[vx,vy,]heading), out_scores, out_labels
- * (+label_offset), out_num[b].  *status bit 0: more than 4096 cells tied inside one score bin
+ * (int64 as the reference's label_preds, +label_offset), out_num[b].  *status bit 0: more than 4096 cells tied inside one score bin
  * at the pre_max cut-off (excess dropped).  Score ties are ordered by ascending cell index.
  * ------------------------------------------------------------------------ */
 typedef struct {
@@ -238,7 +238,7 @@ typedef struct {
 size_t pn_decode_workspace_bytes(const pnDecodeGroup* groups, int num_groups, int batch, int box_dim);
 int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
                          const pnDecodeCommon* common, int box_dim, int out_cap,
-                         float* out_boxes, float* out_scores, int32_t* out_labels,
+                         float* out_boxes, float* out_scores, int64_t* out_labels,
                          int32_t* out_num, int32_t* status, void* workspace,
                          size_t workspace_bytes, pnStream stream);
 
@@ -273,7 +273,7 @@ int pn_centerhead_select(const pnDecodeGroup* groups, int num_groups, const pnDe
                          size_t workspace_bytes, pnStream stream);
 int pn_centerhead_detect_selected(const pnDecodeGroup* groups, int num_groups, const pnDecodeCommon* common,
                                   int box_dim, int out_cap, float* out_boxes, float* out_scores,
-                                  int32_t* out_labels, int32_t* out_num, int32_t* status, void* workspace,
+                                  int64_t* out_labels, int32_t* out_num, int32_t* status, void* workspace,
                                   size_t workspace_bytes, pnStream stream);
 
 /* ------------------------------------------------------------------------

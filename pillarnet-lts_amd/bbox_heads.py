@@ -241,9 +241,9 @@ class CenterHead(nn.Module):
             gi = t - p["tasks"][0]
             for k in (range(self.num_classes[t]) if multi_class else [None]):
                 g = _lib.pnDecodeGroup()
-                g.maps = hm[gi].data_ptr()
+                g.maps = hm[:, gi].data_ptr()          # this task's columns of the [rows, G, npad_h] map
                 g.height, g.width, g.channels, g.num_classes = xs.H, xs.W, self.num_classes[t], self.num_classes[t]
-                g.row_stride = p["npad_h"]
+                g.row_stride = p["G"] * p["npad_h"]
                 g.has_vel, g.has_iou = has_vel, has_iou
                 g.class_filter = -1 if k is None else k
                 g.label_offset = label_offset
@@ -300,7 +300,7 @@ class CenterHead(nn.Module):
             g0 = g1
         boxes = torch.empty((B, out_cap, nd), dtype=torch.float32, device=dev)
         scores = torch.empty((B, out_cap), dtype=torch.float32, device=dev)
-        labels = torch.empty((B, out_cap), dtype=torch.int32, device=dev)
+        labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
         num = torch.empty(B + 1, dtype=torch.int32, device=dev)
         rc = L.pn_centerhead_detect_selected(G, Gd, ctypes.byref(common), nd, out_cap, _lib.ptr(boxes), _lib.ptr(scores),
                                              _lib.ptr(labels), _lib.ptr(num), ctypes.c_void_p(num.data_ptr() + 4 * B),
@@ -315,7 +315,7 @@ class CenterHead(nn.Module):
         if not metas:
             metas = [None] * B
         return [{"box3d_lidar": boxes[b, :counts[b]], "scores": scores[b, :counts[b]],
-                 "label_preds": labels[b, :counts[b]].long(), "metadata": metas[b]} for b in range(B)]
+                 "label_preds": labels[b, :counts[b]], "metadata": metas[b]} for b in range(B)]
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
@@ -389,7 +389,7 @@ class CenterHead(nn.Module):
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         boxes = torch.empty((B, out_cap, nd), dtype=torch.float32, device=dev)
         scores = torch.empty((B, out_cap), dtype=torch.float32, device=dev)
-        labels = torch.empty((B, out_cap), dtype=torch.int32, device=dev)
+        labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
         num = torch.empty(B + 1, dtype=torch.int32, device=dev)   # [B] counts + status word (both written)
         rc = L.pn_centerhead_detect(G, len(groups), ctypes.byref(common), nd, out_cap, _lib.ptr(boxes),
                                     _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(num),
@@ -408,5 +408,5 @@ class CenterHead(nn.Module):
         for b in range(B):
             n = counts[b]
             out.append({"box3d_lidar": boxes[b, :n], "scores": scores[b, :n],
-                        "label_preds": labels[b, :n].long(), "metadata": metas[b]})
+                        "label_preds": labels[b, :n], "metadata": metas[b]})
         return out

@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void gather_detections_kernel(
     const float* __restrict__ cand_boxes, const float* __restrict__ cand_scores,
     const int32_t* __restrict__ cand_labels, const int32_t* __restrict__ keep,
     const int32_t* __restrict__ num_keep, float* __restrict__ out_boxes,
-    float* __restrict__ out_scores, int32_t* __restrict__ out_labels, int32_t* __restrict__ out_num) {
+    float* __restrict__ out_scores, int64_t* __restrict__ out_labels, int32_t* __restrict__ out_num) {
   // one block per (group, sample): every block sums the kept counts of the earlier groups itself (all loads
   // independent), so the groups copy in parallel instead of one after the other
   const int g = blockIdx.x, b = blockIdx.y;
@@ -854,7 +854,7 @@ static int decode_score_select(const DecodeSetup& st, int num_groups, int box_di
 
 // NMS on the sorted candidate boxes of every set, then the per-sample concatenation
 static int decode_nms_gather(const DecodeSetup& st, int num_groups, int box_dim, int out_cap, float* out_boxes,
-                             float* out_scores, int32_t* out_labels, int32_t* out_num, int32_t* status, char* ws,
+                             float* out_scores, int64_t* out_labels, int32_t* out_num, int32_t* status, char* ws,
                              hipStream_t stream) {
   const DecodeLayout& L = st.L;
   const int S = st.S, pre_cap = st.pre_cap, B = st.C.B;
@@ -876,7 +876,7 @@ static int decode_nms_gather(const DecodeSetup& st, int num_groups, int box_dim,
 
 extern "C" int pn_centerhead_detect(const pnDecodeGroup* groups, int num_groups,
                                     const pnDecodeCommon* common, int box_dim, int out_cap,
-                                    float* out_boxes, float* out_scores, int32_t* out_labels,
+                                    float* out_boxes, float* out_scores, int64_t* out_labels,
                                     int32_t* out_num, int32_t* status, void* workspace,
                                     size_t workspace_bytes, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -921,7 +921,7 @@ extern "C" int pn_centerhead_select_capacity(const pnDecodeGroup* groups, int nu
 
 extern "C" int pn_centerhead_detect_selected(const pnDecodeGroup* groups, int num_groups,
                                              const pnDecodeCommon* common, int box_dim, int out_cap,
-                                             float* out_boxes, float* out_scores, int32_t* out_labels,
+                                             float* out_boxes, float* out_scores, int64_t* out_labels,
                                              int32_t* out_num, int32_t* status, void* workspace,
                                              size_t workspace_bytes, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -555,8 +555,8 @@ static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
 //                the level has fewer 256-row tiles than CUs
 //   Cout <= 128  256 x 128, 4 compute waves of 64 x 128
 //   wider        128 x 256 with 8 compute waves of 64 x 64 + 8 loaders (2-6 % ahead of 4 x (64 x 128) + 4 on every
-//                256-wide shape); 64 x 128 unit-stage tiles when the level is small (a 90 x 90 map is 64 tiles of
-//                128 rows on 256 CUs: filling the chip wins 2x although every tile then streams all its weights)
+//                256-wide shape); 128 x 64 unit-stage tiles when the level is small (a 90 x 90 map is 64 tiles of
+//                128 x 256 on 256 CUs: filling the chip wins 2x although every tile then streams its weights itself)
 // PN_GG_WIN_CFG (tuning / tests): P = per-tap stages everywhere, D = 128 x 256 on 4 + 4 waves, T = 128 x 128 tiles
 // with a 2-deep weight ring (two workgroups per CU; within 3 % of the default on every shape measured).
 template <typename TOut>
@@ -581,8 +581,13 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   }
   if (f == 'T') return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
   if (N <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
-  if (work_rows <= 128 * 160 && N % 128 == 0)   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
-    return launch_win<64, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);
+  if (work_rows <= 128 * 160 && N % 128 == 0) {   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
+    // 128 x 64 tiles (4 compute waves of 32 x 64 + 4 loaders): as many workgroups as 64 x 128 tiles give, but a
+    // workgroup streams half the weight bytes for the same MFMAs (the level is bound by DMA issue): +2 % on the
+    // frame.  (WMAX 288: a stride-2 run is 2 * 128 + 3 rows.)  'Q' keeps the 64 x 128 shape for comparison.
+    if (f == 'Q') return launch_win<64, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);
+    return launch_win<128, 64, 4, 1, 4, 64, 288, TOut, true>(a, groups, stream);
+  }
   if (f == 'D') return launch_win<128, 256, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
   return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
 }

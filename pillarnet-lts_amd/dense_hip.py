@@ -443,7 +443,13 @@ class LazyHeadPlan:
                 for g, (_, o) in enumerate(hm_steps):
                     wz_hm[g, :, :o.out_channels] = o.weight.detach().float().permute(2, 3, 0, 1).reshape(9, o.out_channels, tw)
                     b_hm[g, :o.out_channels] = o.bias.detach().float()
-                wz_hm = wz_hm.reshape(G, 1, 9 * npad_h, tw).to(torch.bfloat16).contiguous()
+                # all tasks' heat-map output convs as ONE 1-tap GEMM over the [rows, G*tw] tower map: column
+                # tap*(G*npad_h) + g*npad_h + c, block g of the K axis; the zero blocks add exact zeros, and the
+                # tap sum then reads G*npad_h contiguous floats per (row, tap) instead of npad_h
+                wz_all = torch.zeros((9, G, npad_h, G, tw), dtype=torch.float32, device=dev)
+                for g in range(G):
+                    wz_all[:, g, :, g, :] = wz_hm[g]
+                wz_hm = wz_all.reshape(1, 9 * G * npad_h, G * tw).to(torch.bfloat16).contiguous()
                 w_reg = torch.stack([torch.cat([s.w for s, _ in r], dim=1) for r in reg]).contiguous()   # [G, 9, kin_r, cin]
                 sc_reg = torch.stack([torch.cat([s.scale for s, _ in r]) for r in reg]).contiguous()
                 sh_reg = torch.stack([torch.cat([s.shift for s, _ in r]) for r in reg]).contiguous()
@@ -466,7 +472,7 @@ class LazyHeadPlan:
                                     ones_r=torch.ones(9 * npad_r, device=dev), zeros_r=torch.zeros(9 * npad_r, device=dev))
 
     def run_hm(self, feats):
-        """-> per level: (shared Rows, hm maps fp32 [G, rows, npad_h])."""
+        """-> per level: (shared Rows, hm maps fp32 [rows, G, npad_h])."""
         L = _lib.lib()
         out = {}
         for lvl, p in self.levels.items():
@@ -475,16 +481,13 @@ class LazyHeadPlan:
             rows, dev, G = x.B * Ho * Wo, x.t.device, p["G"]
             tow = torch.empty((rows, G * p["tw"]), dtype=torch.bfloat16, device=dev)
             _launch(x.t, p["cin"], nbr, 9, rows, p["w_hm"], p["sc_hm"], p["sh_hm"], True, tow, G * p["tw"], in_ld=x.ld)
-            nz = 9 * p["npad_h"]
-            z = torch.empty((rows, G * nz), dtype=torch.float32, device=dev)
-            rc = L.pn_gather_gemm_grouped(_lib.ptr(tow), p["tw"], G * p["tw"], rows, p["tw"], None, 0, 1, rows,
-                                          _lib.ptr(p["wz_hm"]), nz, G, _lib.ptr(p["ones_h"]), _lib.ptr(p["zeros_h"]), 0,
-                                          _lib.ptr(z), G * nz, nz, 1, None, 0, _lib.current_stream(dev))
-            _lib.check(rc, "pn_gather_gemm_grouped")
-            hm = torch.empty((G, rows, p["npad_h"]), dtype=torch.float32, device=dev)
-            rc = L.pn_tap_sum(_lib.ptr(z), _lib.PN_DTYPE_F32, G * nz, nz, _lib.ptr(nbr), nbr.shape[1], rows, p["npad_h"],
-                              G, _lib.ptr(p["b_hm"]), _lib.ptr(hm), p["npad_h"], rows * p["npad_h"],
-                              _lib.current_stream(dev))
+            C = G * p["npad_h"]
+            z = torch.empty((rows, 9 * C), dtype=torch.float32, device=dev)
+            _launch(tow, G * p["tw"], None, 1, rows, p["wz_hm"], p["ones_h"], p["zeros_h"], False, z, 9 * C,
+                    fp32_out=True, in_ld=G * p["tw"])
+            hm = torch.empty((rows, G, p["npad_h"]), dtype=torch.float32, device=dev)     # task g: hm[:, g, :]
+            rc = L.pn_tap_sum(_lib.ptr(z), _lib.PN_DTYPE_F32, 9 * C, 0, _lib.ptr(nbr), nbr.shape[1], rows, C, 1,
+                              _lib.ptr(p["b_hm"]), _lib.ptr(hm), C, 0, _lib.current_stream(dev))
             _lib.check(rc, "pn_tap_sum")
             out[lvl] = (x, hm)
         return out
