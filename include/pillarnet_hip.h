@@ -409,6 +409,17 @@ int pn_merge_sweeps(const float* raw, int raw_dim, int use_dim, const int32_t* s
                     const float* time_lag, const uint8_t* filter_close, float radius, float* out,
                     int32_t* out_count, void* workspace, size_t workspace_bytes, pnStream stream);
 
+/* ------------------------------------------------------------------------
+ * Host-side hard voxelizer: the `Voxelization(cfg=voxel_generator)` pipeline step of the legacy configs,
+ * det3d/ops/point_cloud/point_cloud_ops.py:112-184 (points_to_voxel; numba kernels :8-109).  CPU, as in the
+ * reference (dataloader workers): HOST pointers.  points [n, feats] fp32; grid_map int32 per voxel of the grid
+ * (z, y, x order when reverse_index), all -1 on entry; voxels [max_voxels, max_points, feats] and num_points
+ * zeroed on entry; coors [max_voxels, 3].  Returns the number of voxels (>= 0) or PN_EINVAL.
+ * ------------------------------------------------------------------------ */
+int pn_points_to_voxel(const float* points, long long n, int feats, const float* voxel_size, const float* range,
+                       int reverse_index, int max_points, int max_voxels, int32_t* grid_map, float* voxels,
+                       int32_t* coors, int32_t* num_points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,8 @@ from .spconv import SparseConvTensor  # noqa: F401
 from .config import Config, ConfigDict  # noqa: F401
 from .registry import (BACKBONES, DETECTORS, HEADS, NECKS, READERS, Registry,  # noqa: F401
                        build_from_cfg)
-from . import readers, backbones, necks, bbox_heads, detectors, second_stage, loading  # noqa: F401  (fill the registries)
+from . import readers, backbones, necks, bbox_heads, detectors, second_stage, loading, legacy  # noqa: F401  (fill the registries)
 from .builder import (build_backbone, build_detector, build_head, build_neck,  # noqa: F401
                       build_reader)
 from .checkpoint import load_checkpoint, load_state_dict, resume, save_checkpoint  # noqa: F401
+from .wire import collate_kitti  # noqa: F401

@@ -74,10 +74,26 @@ class PackedPreds(dict):
 
 @HEADS.register_module
 class CenterHead(nn.Module):
+    _LEGACY_KEYS = ("dataset", "weight", "share_conv_channel", "dcn_head", "iou_reg", "order_class_names",
+                    "init_bias", "num_hm_conv")
+
     def __init__(self, tasks: List[dict], in_channels: List, code_weights: List, common_heads=dict(),
                  logger=None, share_channel=64, reg_iou=None, pillar_size=0.1,
-                 point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4]):
+                 point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4], **legacy):
+        from_legacy = bool(legacy) or isinstance(in_channels, int) or any("stride" not in t for t in tasks)
+        if from_legacy:
+            # kwargs of the legacy configs (configs/nusc/**, configs/waymo/**): see legacy.legacy_head_kwargs
+            unknown = set(legacy) - set(self._LEGACY_KEYS)
+            if unknown:
+                raise TypeError(f"CenterHead.__init__() got unexpected keyword arguments {sorted(unknown)}")
+            from .legacy import legacy_head_kwargs
+            kw = legacy_head_kwargs(dict(legacy, tasks=tasks, in_channels=in_channels, code_weights=code_weights,
+                                         common_heads=common_heads, logger=logger, share_channel=share_channel,
+                                         reg_iou=reg_iou, pillar_size=pillar_size,
+                                         point_cloud_range=point_cloud_range))
+            tasks, in_channels, share_channel, reg_iou = kw["tasks"], kw["in_channels"], kw["share_channel"], kw["reg_iou"]
         super().__init__()
+        self.legacy_geometry = from_legacy       # stride / pillar size / range then come from test_cfg
         self.num_classes = [len(t["class_names"]) for t in tasks]
         self.class_names = [t["class_names"] for t in tasks]
         self.task_strides = [int(t["stride"]) for t in tasks]
@@ -86,7 +102,7 @@ class CenterHead(nn.Module):
         self.point_cloud_range = point_cloud_range
         # feature maps arrive ordered by descending stride (center_head.py:75-79)
         strides = sorted(set(self.task_strides), reverse=True)
-        assert len(in_channels) == len(strides)
+        assert len(in_channels) == len(strides), (in_channels, strides)
         self.task_idx = [strides.index(s) for s in self.task_strides]
         self.use_iou = "iou" in common_heads
         self.use_reg_iou = reg_iou is not None
@@ -410,3 +426,17 @@ class CenterHead(nn.Module):
             out.append({"box3d_lidar": boxes[b, :n], "scores": scores[b, :n],
                         "label_preds": labels[b, :n], "metadata": metas[b]})
         return out
+
+
+def resolve_legacy_geometry(head, test_cfg):
+    """fill a legacy head's stride / pillar size / range from test_cfg (out_size_factor, voxel_size, pc_range)."""
+    if test_cfg is None or not getattr(head, "legacy_geometry", False):
+        return
+    osf = int(test_cfg.get("out_size_factor", 8))
+    head.task_strides = [osf if s == 0 else s for s in head.task_strides]
+    vs = test_cfg.get("voxel_size", None)
+    if vs is not None:
+        head.pillar_size = float(vs[0])
+    rng = test_cfg.get("pc_range", None)
+    if rng is not None and len(rng) >= 2:
+        head.point_cloud_range = list(rng[:2]) + list(head.point_cloud_range[2:])

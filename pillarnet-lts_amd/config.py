@@ -55,6 +55,45 @@ class ConfigDict(dict):
         return self[k]
 
 
+def get_downsample_factor(model_config):
+    """det3d/utils/config_tool.py:39-53 (the module imports protobuf for its other, KITTI-era helpers):
+    product of the neck's down-sampling strides, over its last up-sampling stride, times the backbone's."""
+    try:
+        neck_cfg = model_config["neck"]
+    except (KeyError, TypeError):
+        model_config = model_config["first_stage_cfg"]
+        neck_cfg = model_config["neck"]
+    factor = 1.0
+    for s in neck_cfg.get("ds_layer_strides", [1]):
+        factor *= s
+    if len(neck_cfg.get("us_layer_strides", [])) > 0:
+        factor /= neck_cfg.get("us_layer_strides", [])[-1]
+    factor = int(factor * model_config["backbone"]["ds_factor"])
+    assert factor > 0
+    return factor
+
+
+def _ensure_det3d_config_tool():
+    """The legacy configs (configs/nusc/**, configs/waymo/**) start with
+    `from det3d.utils.config_tool import get_downsample_factor`.  Where the reference package is not
+    importable, that name resolves to the function above."""
+    import types
+    try:
+        import det3d.utils.config_tool  # noqa: F401
+        return
+    except Exception:
+        pass
+    for name in ("det3d", "det3d.utils", "det3d.utils.config_tool"):
+        if name not in sys.modules or not hasattr(sys.modules[name], "__path__") and name != "det3d.utils.config_tool":
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    tool = sys.modules["det3d.utils.config_tool"]
+    tool.get_downsample_factor = get_downsample_factor
+    sys.modules["det3d"].utils = sys.modules["det3d.utils"]
+    sys.modules["det3d.utils"].config_tool = tool
+
+
 class Config:
     @staticmethod
     def fromfile(filename):
@@ -68,6 +107,7 @@ class Config:
             spec = importlib.util.spec_from_file_location(name, filename)
             mod = importlib.util.module_from_spec(spec)
             sys.path.insert(0, osp.dirname(filename))
+            _ensure_det3d_config_tool()
             try:
                 spec.loader.exec_module(mod)
             finally:

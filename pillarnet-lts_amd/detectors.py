@@ -33,6 +33,9 @@ class SingleStageDetector(BaseDetector):
         self.bbox_head = builder.build_head(bbox_head)
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
+        if hasattr(self.bbox_head, "task_strides"):
+            from .bbox_heads import resolve_legacy_geometry      # legacy head dicts carry no stride / pillar size
+            resolve_legacy_geometry(self.bbox_head, self.test_cfg)
         self.compute_dtype = torch.float32
         self.init_weights(pretrained=pretrained)
 
@@ -68,7 +71,10 @@ class SingleStageDetector(BaseDetector):
         for m in (self.backbone, getattr(self, "neck", None), self.bbox_head):
             if m is not None:
                 m._dense_hip = use_hip
-        dense = [getattr(self.backbone, "conv5", None), getattr(self, "neck", None), self.bbox_head]
+        inner = getattr(self.backbone, "net", None)      # legacy encoders wrap the live sparse stack
+        if inner is not None:
+            inner._dense_hip = use_hip
+        dense = [getattr(inner or self.backbone, "conv5", None), getattr(self, "neck", None), self.bbox_head]
         for m in dense:
             if m is None:
                 continue
@@ -96,7 +102,9 @@ class PillarNet(SingleStageDetector):
 
     def extract_feat(self, data):
         sp = self.reader(data)
-        if self.compute_dtype != sp.features_cap.dtype:
+        if isinstance(sp, dict):     # legacy `Identity` reader: the backbone pillarises the points itself
+            self.backbone.compute_dtype = self.compute_dtype
+        elif self.compute_dtype != sp.features_cap.dtype:
             sp = sp.replace_feature(sp.features_cap.to(self.compute_dtype))
         pillar_features = self.backbone(sp)
         bev_features = self.neck(pillar_features) if self.with_neck else None

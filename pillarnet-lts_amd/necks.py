@@ -84,7 +84,15 @@ class _NeckBase(nn.Module):
 class RPNV1(_NeckBase):
     """rpn.py:138-207: conv5 stack -> 2x up -> cat conv4 -> stack (nuScenes, stride-8 head)."""
 
-    def __init__(self, layer_nums, num_filters, in_channels, norm_cfg=None, logger=None, **kwargs):
+    def __new__(cls, layer_nums=None, num_filters=None, in_channels=None, norm_cfg=None, logger=None, **kwargs):
+        if "ds_num_filters" in kwargs:       # legacy kwargs (configs/nusc/**): legacy.legacy_rpn_v translates
+            from .legacy import legacy_rpn_v
+            return legacy_rpn_v("RPNV1", layer_nums, dict(kwargs, logger=logger))
+        return super().__new__(cls)
+
+    def __init__(self, layer_nums, num_filters=None, in_channels=None, norm_cfg=None, logger=None, **kwargs):
+        if "ds_num_filters" in kwargs:
+            return                           # built by __new__ from the translated kwargs
         super().__init__()
         self.norm_cfg = norm_cfg or dict(type="BN", momentum=0.01, eps=1e-3)
         self.block_5 = _stack(self.norm_cfg, in_channels[0], in_channels[0], layer_nums[0])
@@ -109,7 +117,15 @@ class RPNV1(_NeckBase):
 class RPNV2(_NeckBase):
     """rpn.py:211-272: same shape one level down (conv4 stack -> up -> cat conv3)."""
 
-    def __init__(self, layer_nums, in_channels, num_filters, norm_cfg=None, logger=None):
+    def __new__(cls, layer_nums=None, in_channels=None, num_filters=None, norm_cfg=None, logger=None, **kwargs):
+        if "ds_num_filters" in kwargs:       # legacy kwargs: legacy.legacy_rpn_v translates
+            from .legacy import legacy_rpn_v
+            return legacy_rpn_v("RPNV2", layer_nums, dict(kwargs, logger=logger))
+        return super().__new__(cls)
+
+    def __init__(self, layer_nums, in_channels=None, num_filters=None, norm_cfg=None, logger=None, **kwargs):
+        if "ds_num_filters" in kwargs:
+            return                           # built by __new__ from the translated kwargs
         super().__init__()
         self.norm_cfg = norm_cfg or dict(type="BN", momentum=0.01, eps=1e-3)
         self.block_4 = _stack(self.norm_cfg, in_channels[0], in_channels[0], layer_nums[0])
@@ -184,8 +200,10 @@ class RPN(nn.Module):
     """rpn.py:14-134: the SECOND-style multi-stride RPN (legacy configs); takes a dense tensor."""
 
     def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
-                 in_channels, norm_cfg=None, logger=None, **kwargs):
+                 in_channels=None, norm_cfg=None, logger=None, **kwargs):
         super().__init__()
+        if in_channels is None:
+            in_channels = kwargs.pop("num_input_features")      # the legacy configs' name for it
         self._layer_strides, self._num_filters, self._layer_nums = ds_layer_strides, ds_num_filters, layer_nums
         self._upsample_strides, self._num_upsample_filters = us_layer_strides, us_num_filters
         self._norm_cfg = norm_cfg or _BN
@@ -223,6 +241,9 @@ class RPN(nn.Module):
                 xavier_init(m, distribution="uniform")
 
     def forward(self, x):
+        if isinstance(x, dict):      # PillarNet hands over the backbone's stage dict: the stride-8 map
+            x = x["conv4"]
+            x = x.dense() if hasattr(x, "dense") else x
         ups = []
         for i, blk in enumerate(self.blocks):
             x = blk(x)

@@ -430,9 +430,11 @@ def _fc_stack(cfg_list, cin, cout, dp_ratio, conv=True):
 class RoIMIXHead(nn.Module):
     """roi_mix_head.py:17-122 + roi_head_template.py:22-40,189-219 (inference)."""
 
-    def __init__(self, in_channels, model_cfg, num_class=1, code_size=7, add_box_param=False, test_cfg=None,
+    def __init__(self, in_channels=None, model_cfg=None, num_class=1, code_size=7, add_box_param=False, test_cfg=None,
                  mixer_type=None, num_patches=49, **kwargs):
         super().__init__()
+        if in_channels is None:
+            in_channels = kwargs.pop("input_channels")          # the legacy configs' name for it
         self.model_cfg, self.test_cfg, self.num_class = model_cfg, test_cfg, num_class
         self.code_size, self.add_box_param, self.num_patches = code_size, add_box_param, num_patches
         if mixer_type == "MLPMixer":
@@ -560,8 +562,10 @@ class RoIMIXHead(nn.Module):
 class PointHead(nn.Module):
     """point_head_simple.py:14-98 (the auxiliary foreground classifier on the RoI grid points)."""
 
-    def __init__(self, in_channels, num_class, model_cfg, **kwargs):
+    def __init__(self, in_channels=None, num_class=1, model_cfg=None, **kwargs):
         super().__init__()
+        if in_channels is None:
+            in_channels = kwargs.pop("input_channels")          # the legacy configs' name for it
         self.model_cfg, self.num_class = model_cfg, num_class
         layers, c_in = [], in_channels
         for c in model_cfg["CLS_FC"]:
