@@ -366,6 +366,18 @@ int pn_scatter_max_grad(const float* grad_out, const int32_t* arg, int M, int C,
  * with nbr[k*nbr_stride + m] == j, or -1 (inv is fully initialised here). */
 int pn_spconv_invert_rules(const int32_t* nbr, int nbr_stride, const int32_t* out_count_dev,
                            int out_cap, int32_t* inv, int inv_stride, pnStream stream);
+/* Weight gradient of a rulebook convolution, fp32:
+ *   dw[co][tap][ci] = sum_{m < rows} grad_out[m][co] * x[nbr[tap*nbr_stride + m]][ci]      (nbr < 0: no term)
+ * which is the layout of an spconv 2.x weight [cout, 3, 3, cin] for ntaps = 9.  Replaces the weight-gradient
+ * half of spconv's backward (third-party spconv-cu114, reached through spconv.pytorch.SubMConv2d / SparseConv2d
+ * at det3d/models/backbones/base.py:9-36; the reference holds no source for it).  nbr NULL = identity
+ * (ntaps must be 1: a plain X^T G product).  cin, cout multiples of 32; x_ld / g_ld = row strides in floats
+ * (0: cin / cout); count_dev optional device row count.  Partial sums per site chunk live in `workspace`
+ * (pn_spconv_wgrad_workspace_bytes) and are added in a fixed order: results are bit-reproducible. */
+size_t pn_spconv_wgrad_workspace_bytes(int rows, int cin, int cout, int ntaps);
+int pn_spconv_wgrad(const float* x, int cin, int x_ld, const int32_t* nbr, int nbr_stride, int ntaps,
+                    const int32_t* count_dev, int rows, const float* grad_out, int cout, int g_ld,
+                    float* dw, void* workspace, size_t workspace_bytes, pnStream stream);
 
 /* ------------------------------------------------------------------------
  * RoI pillar pooling of Pillar R-CNN's second stage: a grid x grid lattice over every rotated RoI,

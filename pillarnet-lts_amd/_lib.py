@@ -110,6 +110,9 @@ SIGNATURES = {
                                c_void_p]),
     "pn_scatter_max_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pn_spconv_invert_rules": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "pn_spconv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "pn_spconv_wgrad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_roi_grid_pool": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "pn_points_in_boxes_2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

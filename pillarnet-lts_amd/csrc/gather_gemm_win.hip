@@ -409,7 +409,6 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         if (a.diag != 1) {
 #pragma unroll
           for (int t = 0; t < 3; ++t) STAGE_MFMA(abase, wsm + ((u & 1) * 3 + t) * WBUF, t);
-          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // opaque-asm MFMA -> VALU read hazard
         }
         if (u + 1 < nfills) {
 #pragma unroll
@@ -430,7 +429,6 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         const char* abase = smem + ((win ? s / TPG : s) & 1) * ABUF;
         if (a.diag != 1) {
           STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
-          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // opaque-asm MFMA -> VALU read hazard
         }
         if (s + 1 < nstages) ROW_TABLE(s + 1, 0);   // static rulebook tile: next stage's rows before the barrier
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
@@ -440,6 +438,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       }
     }
   }
+  // the MFMAs sit in opaque asm: the hazard checker does not know that the VALU reads of `acc` below follow them
+  // (inside the loop no VALU instruction touches the accumulators)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   GGW_STAMP(wave == 0, 2);
 
   // ---- epilogue.  D row = output channel (reg&3) + 8*(reg>>2) + 4*lh, D col = site lr.  The compute

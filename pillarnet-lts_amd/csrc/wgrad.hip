@@ -1,0 +1,162 @@
+// Weight gradient of a rulebook convolution in fp32 (training runs in fp32, as the reference does):
+//   dW[co][tap][ci] = sum_m G[m][co] * X[nbr[tap][m]][ci]
+// i.e. per tap a [cout x sites] . [sites x cin] product whose long dimension is the site list.  spconv's own
+// backward (the reference calls it through spconv.pytorch, a third-party package) does the same per tap with a
+// gather + GEMM; here the gather is the B-operand load itself.
+//
+// Shape of the work: the output is small (<= 9 x 256 x 256) and the reduction long (1e5 .. 1e6 sites), so the site
+// list is cut into chunks, every (chunk, tap, 64x64 output tile) is one wavefront, and the per-chunk partial
+// sums are added up by a second kernel in a fixed order (bit-reproducible: no float atomics).  A wavefront reads
+// its operands straight from global memory into the layout v_mfma_f32_32x32x2_f32 wants -- lane l holds row
+// l % 32 of site l / 32 -- which is a 128-B run of one gradient row and of one gathered input row per half wave:
+// no LDS staging, no transposes.  The fp32 MFMA takes 64 cycles, so two operand loads per MFMA are far from
+// the load path's limit; 4 waves per SIMD hide the index -> row dependent latency.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct WgradArgs {
+  const float* x;      // [n_in, x_ld]
+  const float* g;      // [rows, g_ld]
+  const int32_t* nbr;  // [ntaps][nbr_stride] input row of (tap, output site) or -1; NULL: identity (ntaps == 1)
+  const int32_t* count;
+  float* partial;      // [chunks][ntaps][cout][cin]
+  int x_ld, g_ld, nbr_stride, rows, cin, cout, ntaps, chunk_sites;
+};
+
+template <int TCO, int TCI, int U>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+  const int tiles_ci = a.cin / (32 * TCI), ntiles = tiles_ci * (a.cout / (32 * TCO));
+  const int tile = blockIdx.z * (blockDim.x >> 6) + wave;
+  if (tile >= ntiles) return;                       // wave-uniform
+  const int co0 = (tile / tiles_ci) * 32 * TCO, ci0 = (tile % tiles_ci) * 32 * TCI;
+  const int tap = blockIdx.y, chunk = blockIdx.x;
+  int M = a.count ? *a.count : a.rows;
+  if (M > a.rows) M = a.rows;
+  const int s_begin = chunk * a.chunk_sites;
+  const int s_end = min(M, s_begin + a.chunk_sites);
+  f32x16 acc[TCO][TCI];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int32_t* nbr = a.nbr ? a.nbr + (size_t)tap * a.nbr_stride : nullptr;
+  for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
+    float ga[U][TCO], xb[U][TCI];
+    int idx[U];
+#pragma unroll
+    for (int p = 0; p < U; ++p) {                   // two sites per MFMA: the half wave picks one
+      const int site = s0 + 2 * p + lh;
+      idx[p] = site < s_end ? (nbr ? nbr[site] : site) : -1;
+    }
+#pragma unroll
+    for (int p = 0; p < U; ++p) {
+      const int site = s0 + 2 * p + lh;
+      const bool ok = site < s_end;
+      const float* gr = a.g + (size_t)(ok ? site : 0) * a.g_ld + co0 + lr;
+      const float* xr = a.x + (size_t)(idx[p] >= 0 ? idx[p] : 0) * a.x_ld + ci0 + lr;
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) ga[p][t] = ok ? gr[32 * t] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TCI; ++t) xb[p][t] = idx[p] >= 0 ? xr[32 * t] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < U; ++p)
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[p][i], xb[p][j], acc[i][j], 0, 0, 0);
+  }
+  // D[i][j]: lane holds column j = lr (input channel) and rows i = (r & 3) + 8 * (r >> 2) + 4 * lh (output channel)
+  float* P = a.partial + ((size_t)chunk * a.ntaps + tap) * (size_t)a.cout * a.cin;
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        P[(size_t)co * a.cin + ci0 + 32 * j + lr] = acc[i][j][r];
+      }
+}
+
+// dw[co][tap][ci] = sum over chunks, in chunk order per lane group and a fixed tree over the 8 groups
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* partial, int chunks, int ntaps, int cout, int cin,
+                                                           float* dw) {
+  __shared__ float part[8][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const size_t n_out = (size_t)ntaps * cout * cin;
+  float s = 0.f;
+  if ((size_t)o < n_out)
+    for (int c = grp; c < chunks; c += 8) s += partial[(size_t)c * n_out + o];
+  part[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && (size_t)o < n_out) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+    const int ci = o % cin, co = (o / cin) % cout, tap = o / (cin * cout);
+    dw[((size_t)co * ntaps + tap) * cin + ci] = t;
+  }
+}
+
+static int wgrad_plan(int rows, int cin, int cout, int ntaps, int* chunk_sites) {
+  // enough wavefronts to fill the chip a few times over, partial sums within 64 MiB
+  const int tco = cout % 64 == 0 ? 2 : 1, tci = cin % 64 == 0 ? 2 : 1;
+  const long long ntiles = (long long)(cout / (32 * tco)) * (cin / (32 * tci));
+  long long chunks = 8192 / (ntiles * ntaps);
+  const long long by_mem = (64ll << 20) / ((long long)ntaps * cout * cin * 4);
+  if (chunks > by_mem) chunks = by_mem;
+  const long long by_rows = (rows + 255) / 256;
+  if (chunks > by_rows) chunks = by_rows;
+  if (chunks < 1) chunks = 1;
+  int per = (int)((rows + chunks - 1) / chunks);
+  per = (per + 15) / 16 * 16;
+  if (per < 16) per = 16;
+  *chunk_sites = per;
+  return (int)((rows + per - 1) / per > 0 ? (rows + per - 1) / per : 1);
+}
+
+extern "C" size_t pn_spconv_wgrad_workspace_bytes(int rows, int cin, int cout, int ntaps) {
+  if (rows < 0 || cin <= 0 || cout <= 0 || ntaps <= 0) return 0;
+  int per;
+  const int chunks = wgrad_plan(rows, cin, cout, ntaps, &per);
+  return (size_t)chunks * ntaps * cout * cin * sizeof(float);
+}
+
+extern "C" int pn_spconv_wgrad(const float* x, int cin, int x_ld, const int32_t* nbr, int nbr_stride, int ntaps,
+                               const int32_t* count_dev, int rows, const float* grad_out, int cout, int g_ld,
+                               float* dw, void* workspace, size_t workspace_bytes, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !grad_out || !dw || rows < 0 || ntaps <= 0 || ntaps > 9) return PN_EINVAL;
+  if (cin % 32 != 0 || cout % 32 != 0 || cin <= 0 || cout <= 0) return PN_EINVAL;
+  if (!nbr && ntaps != 1) return PN_EINVAL;
+  if (x_ld == 0) x_ld = cin;
+  if (g_ld == 0) g_ld = cout;
+  if (x_ld < cin || g_ld < cout || (nbr && nbr_stride < rows)) return PN_EINVAL;
+  int per;
+  const int chunks = wgrad_plan(rows, cin, cout, ntaps, &per);
+  if (!workspace || workspace_bytes < (size_t)chunks * ntaps * cout * cin * sizeof(float)) return PN_ENOSPC;
+  WgradArgs a;
+  a.x = x; a.g = grad_out; a.nbr = nbr; a.count = count_dev; a.partial = (float*)workspace;
+  a.x_ld = x_ld; a.g_ld = g_ld; a.nbr_stride = nbr_stride; a.rows = rows; a.cin = cin; a.cout = cout;
+  a.ntaps = ntaps; a.chunk_sites = per;
+  const int tco = cout % 64 == 0 ? 2 : 1, tci = cin % 64 == 0 ? 2 : 1;
+  const int ntiles = (cout / (32 * tco)) * (cin / (32 * tci));
+  const int wpb = ntiles < 4 ? ntiles : 4;                 // wavefronts (tiles) per workgroup
+  const dim3 grid(chunks, ntaps, (ntiles + wpb - 1) / wpb), block(64 * wpb);
+  if (tco == 2 && tci == 2) hipLaunchKernelGGL((wgrad_kernel<2, 2, 4>), grid, block, 0, stream, a);
+  else if (tco == 2) hipLaunchKernelGGL((wgrad_kernel<2, 1, 4>), grid, block, 0, stream, a);
+  else if (tci == 2) hipLaunchKernelGGL((wgrad_kernel<1, 2, 4>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, block, 0, stream, a);
+  PN_CHECK_LAUNCH("wgrad_kernel");
+  const size_t n_out = (size_t)ntaps * cout * cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(512), 0, stream,
+                     (const float*)workspace, chunks, ntaps, cout, cin, dw);
+  PN_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return PN_OK;
+}

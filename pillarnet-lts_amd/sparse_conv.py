@@ -9,6 +9,8 @@ chains inside a `SparseSequential` run as ONE kernel with the norm folded into t
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -163,10 +165,30 @@ def _down_rules(x: SparseConvTensor, stride, pad):
     return out_idx, out_num, out_bits, out_rank, nbr, (Ho, Wo), out_cap
 
 
+def rulebook_wgrad(feats, nbr, g, n_out):
+    """dW[co][tap][ci] = sum_m g[m][co] * feats[nbr[tap][m]][ci] -> [cout, ntaps, cin] fp32 (pn_spconv_wgrad).
+    feats / g: fp32 rows (row stride = shape[1] of a contiguous 2-D tensor, or any 2-D view with unit channel
+    stride); nbr [ntaps, stride] int32 or None (identity, one tap)."""
+    cin, cout = feats.shape[1], g.shape[1]
+    ntaps = nbr.shape[0] if nbr is not None else 1
+    dev = g.device
+    assert feats.dtype == torch.float32 and g.dtype == torch.float32 and feats.stride(1) == 1 and g.stride(1) == 1
+    if n_out == 0:
+        return torch.zeros((cout, ntaps, cin), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    gw = torch.empty((cout, ntaps, cin), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(int(L.pn_spconv_wgrad_workspace_bytes(n_out, cin, cout, ntaps)), 1), dtype=torch.uint8, device=dev)
+    rc = L.pn_spconv_wgrad(_lib.ptr(feats), cin, feats.stride(0), _lib.ptr(nbr) if nbr is not None else None,
+                           nbr.shape[1] if nbr is not None else 0, ntaps, None, n_out, _lib.ptr(g), cout, g.stride(0),
+                           _lib.ptr(gw), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev))
+    _lib.check(rc, "pn_spconv_wgrad")
+    return gw
+
+
 class SparseConvFunction(torch.autograd.Function):
     """Differentiable sparse conv on exact fp32 rows.  Forward and data gradient run the HIP
     implicit GEMM (the gradient is the same gather-GEMM over the INVERSE rulebook with transposed
-    tap matrices); the weight gradient is nine small torch GEMMs over gathered rows."""
+    tap matrices); the weight gradient is one fp32 MFMA kernel over the rulebook (pn_spconv_wgrad)."""
 
     @staticmethod
     def forward(ctx, feats, weight, bias, nbr, n_out, inv, count_in, count_out):
@@ -205,13 +227,7 @@ class SparseConvFunction(torch.autograd.Function):
                                                   cin, _lib.current_stream(dev))
                 _lib.check(rc, "pn_spconv_forward (data gradient)")
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros((9, cout, cin), dtype=torch.float32, device=dev)
-            for k in range(9):
-                idx = nbr[k, :n_out].long()
-                valid = idx >= 0
-                if valid.any():
-                    gw[k] = g[valid].t() @ feats[idx[valid]]
-            grad_w = gw.view(3, 3, cout, cin).permute(2, 0, 1, 3).contiguous().to(weight.dtype)
+            grad_w = rulebook_wgrad(feats, nbr, g, n_out).view(cout, 3, 3, cin).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_b = g.sum(0)
         return grad_feats, grad_w, grad_b, None, None, None, None, None
@@ -247,7 +263,8 @@ class ToDenseFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, x):
         ctx.idx = x.indices_cap[: feats.shape[0]].long()
-        return to_dense(x.replace_feature(feats), channels_last=True)
+        out = to_dense(x.replace_feature(feats), channels_last=True)
+        return out.contiguous() if os.environ.get("PN_TRAIN_NCHW") else out
 
     @staticmethod
     def backward(ctx, g):

@@ -24,6 +24,9 @@ def grid_rules(H, W, stride=1):
 
 def run(name, x, nbr, rows, count, cin, cout, iters=20, fp32_out=False):
     w = (torch.randn(9, cout, cin, device=dev) * 0.05).bfloat16()
+    if os.environ.get("GG_BENCH_ZEROS"):     # data-independent timing (power / clock effects of real operands)
+        w.zero_()
+        x = torch.zeros_like(x)
     scale = torch.ones(cout, device=dev)
     shift = torch.zeros(cout, device=dev)
     out = torch.empty((rows, cout), dtype=torch.float32 if fp32_out else torch.bfloat16, device=dev)

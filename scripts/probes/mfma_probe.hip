@@ -54,6 +54,57 @@ void run(float* sink, unsigned long long* cyc) {
          256.0 * NWAVES * iters * 8 * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
+// the window kernel's k-step: G MFMAs on G accumulators, R reads requested at the top, one wait per k-step
+template <int NWAVES, int G, int R>
+__global__ __launch_bounds__(NWAVES * 64) void kstep(int iters, float* sink, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 16384; i += NWAVES * 64) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 127);
+  __syncthreads();
+  f32x16 acc[G];
+  for (int i = 0; i < G; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 f[2][4];
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned addr = base + (unsigned)(((lane & 31) * 128) + ((((lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+  for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(f[0][i]) : "v"(addr + i * 4096));
+  for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(f[1][i]) : "v"(addr + i * 4096));
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f[(ks + 1) & 1][r & 3]) : "v"(addr + ((it + r) & 7) * 4096));
+#pragma unroll
+      for (int m = 0; m < G; ++m)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(f[ks][m & 1]), "v"(f[ks][2 + (m >> 1 & 1)]));
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < G; ++i) s += acc[i][0];
+  if (s == 12345.f) sink[0] = s;
+  if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
+}
+template <int NWAVES, int G, int R>
+void runk(float* sink, unsigned long long* cyc) {
+  const int iters = 2000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  hipFuncSetAttribute((const void*)kstep<NWAVES, G, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kstep<NWAVES, G, R>), dim3(256), dim3(NWAVES * 64), 65536, 0, iters, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double n = iters * 2.0 * G;
+  printf("kstep: waves/CU %2d  %d MFMA + %d ds_read_b128 per k-step : %5.1f ticks/MFMA/wave  %5.2f ns/MFMA/SIMD  (%.0f TF/s chip)\n",
+         NWAVES, G, R, (double)c / n, ms * 1e6 / n / (NWAVES / 4.0), 256.0 * NWAVES * n * 32768.0 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   float* sink; unsigned long long* cyc;
   hipMalloc(&sink, 4); hipMalloc(&cyc, 8);
@@ -63,5 +114,8 @@ int main() {
   run<4, 6, 16>(sink, cyc); run<4, 6, 24>(sink, cyc);
   run<8, 0, 0>(sink, cyc); run<8, 4, 0>(sink, cyc); run<8, 6, 16>(sink, cyc); run<8, 8, 16>(sink, cyc);
   run<1, 6, 16>(sink, cyc);
+  runk<4, 4, 0>(sink, cyc); runk<4, 4, 4>(sink, cyc); runk<8, 4, 0>(sink, cyc); runk<8, 4, 4>(sink, cyc);
+  runk<8, 4, 2>(sink, cyc); runk<4, 8, 6>(sink, cyc); runk<8, 8, 6>(sink, cyc); runk<4, 8, 4>(sink, cyc);
+  runk<8, 8, 0>(sink, cyc);
   return 0;
 }

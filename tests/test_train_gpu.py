@@ -242,3 +242,31 @@ def test_full_size_sparse_conv_gradient_on_a_sampled_window(cuda):
     got = feats.grad[halo].cpu().numpy()[inner]
     # inner sites see all their 3x3 neighbours inside the halo'd patch, so both sides sum the same terms
     np.testing.assert_allclose(got, f.grad.numpy()[inner], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,rows,n_in", [(32, 32, 5003, 4000), (64, 32, 777, 900), (32, 64, 1, 5), (64, 64, 20001, 20001),
+                                                (128, 256, 3000, 2500), (256, 256, 4097, 4097)])
+def test_rulebook_weight_gradient_kernel(cuda, cin, cout, rows, n_in):
+    """pn_spconv_wgrad against the definition in float64: dW[co][tap][ci] = sum_m g[m][co] * x[nbr[tap][m]][ci],
+    missing neighbours (-1) skipped, rows not a multiple of the chunking, row strides wider than the channels;
+    two runs are bit-identical (fixed summation order)."""
+    from pillarnet_lts_amd import sparse_conv
+    gen = torch.Generator().manual_seed(cin * 1000 + cout + rows)
+    x_full = torch.randn((n_in, cin + 32), generator=gen).to(cuda)
+    g_full = torch.randn((rows, cout + 64), generator=gen).to(cuda)
+    x, g = x_full[:, :cin], g_full[:, :cout]
+    nbr = torch.randint(-n_in // 3, n_in, (9, rows + 11), generator=gen).clamp_(min=-1).int().to(cuda)
+    got = sparse_conv.rulebook_wgrad(x, nbr, g, rows)
+    assert got.shape == (cout, 9, cin)
+    want = torch.zeros((cout, 9, cin), dtype=torch.float64, device=cuda)
+    for k in range(9):
+        idx = nbr[k, :rows].long()
+        ok = idx >= 0
+        want[:, k, :] = g[ok].double().t() @ x[idx[ok]].double()
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(scale, 1.0)
+    assert torch.equal(got, sparse_conv.rulebook_wgrad(x, nbr, g, rows))
+    one = sparse_conv.rulebook_wgrad(x[:rows] if rows <= n_in else x_full[:0, :cin], None, g, rows) if rows <= n_in else None
+    if one is not None:
+        np.testing.assert_allclose(one[:, 0].cpu().numpy(), (g.double().t() @ x[:rows].double()).cpu().numpy(),
+                                   rtol=0, atol=2e-5 * max(scale, 1.0))
