@@ -97,7 +97,8 @@ int pn_pillarize(const pnPillarGrid* g, const float* points, int64_t n_points,
  * `[:post_max_size]` slice of rotate_nms_pcdet (det3d/core/bbox/box_torch_ops.py:315-317).
  *
  * boxes      [num_sets, cap, 7] fp32, pcdet frame (x,y,z,dx,dy,dz,heading), each set
- *            sorted by score descending; cap <= 4096
+ *            sorted by score descending; cap <= PN_NMS_MAX_BOXES (the reference's nms_gpu has no limit;
+ *            its callers pass at most nms_pre_max_size = 4096 boxes)
  * counts_dev device int32[num_sets] valid boxes per set (clamped to cap), or NULL to
  *            use the host value count_host for every set
  * thresh_dev device fp32[num_sets] IoU thresholds or NULL -> `thresh` for all; a negative threshold -t
@@ -107,6 +108,7 @@ int pn_pillarize(const pnPillarGrid* g, const float* points, int64_t n_points,
  * keep       [num_sets, keep_stride] int32: positions (into the sorted set) of the
  *            kept boxes, ascending; num_keep device int32[num_sets]
  * ------------------------------------------------------------------------ */
+#define PN_NMS_MAX_BOXES 16384
 size_t pn_nms_workspace_bytes(int num_sets, int cap);
 int pn_nms_rotated(const float* boxes, int num_sets, int cap, const int32_t* counts_dev,
                    int count_host, const float* thresh_dev, float thresh,
@@ -208,8 +210,10 @@ int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, 
  * channel order  reg(2) height(1) dim(3) rot(2: sin, cos) [vel(2)] [iou(1)] hm(num_classes).
  * Output, per sample b: the kept boxes of its groups concatenated in group order --
  * out_boxes [B, out_cap, box_dim] (x,y,z,dx,dy,dz,[vx,vy,]heading), out_scores, out_labels
- * (int64 as the reference's label_preds, +label_offset), out_num[b].  *status bit 0: more than 4096 cells tied inside one score bin
- * at the pre_max cut-off (excess dropped).  Score ties are ordered by ascending cell index.
+ * (int64 as the reference's label_preds, +label_offset), out_num[b].  *status bit 0: more than 4096 cells tied
+ * inside one score bin at the pre_max cut-off (excess dropped); bit 1: see pn_centerhead_detect_selected; bit 2: a
+ * circle-NMS set had more cells above the score threshold than its pre_max (the reference ranks them all, here
+ * the best pre_max).  Score ties are ordered by ascending cell index.
  * ------------------------------------------------------------------------ */
 typedef struct {
   const float* maps;
@@ -353,8 +357,13 @@ int pn_gather_indice(const int32_t* index, int L, const int32_t* indices, int32_
 int pn_gather_feature(const int32_t* index, int L, const float* features, int C, float* outs,
                       pnStream stream);
 /* pillar_cuda.scatter_max_wrapper (scatter_ops.cpp:7-24): out[m,c] = max(0, max_{p: index[p]=m}
- * src[p,c]); arg[m,c] = lowest such p (or -1 where out stayed 0); arg may be NULL.  One pass,
- * deterministic.  workspace: pn_scatter_max_workspace_bytes(M, C). */
+ * src[p,c]); arg may be NULL.  One pass, deterministic.  workspace: pn_scatter_max_workspace_bytes(M, C).
+ * `arg` is NOT the reference's encoding: the reference's second pass (scatter_ops_gpu.cu:24-36) stores the
+ * flat element index p*C + c of whichever maximal point wrote last, zero-valued maxima included; here
+ * arg[m,c] = the POINT index p of the lowest maximal point, and -1 where out stayed 0 (such cells get no
+ * gradient either way: the feature fed to scatter_max is post-ReLU).  It is consumed by pn_scatter_max_grad
+ * below, which expects this encoding; a caller that keeps the reference's own scatter_max_grad kernel must
+ * convert (arg * C + c). */
 size_t pn_scatter_max_workspace_bytes(int M, int C);
 int pn_scatter_max(const int32_t* index, const float* src, int L, int C, int M, int32_t* arg,
                    float* out, void* workspace, size_t workspace_bytes, pnStream stream);

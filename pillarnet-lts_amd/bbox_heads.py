@@ -327,6 +327,9 @@ class CenterHead(nn.Module):
             return self.predict(example, self(x), test_cfg, **kwargs)
         if counts[B] & 1:
             self.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+        if counts[B] & 4:
+            self.logger.warning("CenterHead.predict: circle NMS ranked the best 4096 cells of a task; more were above "
+                                "score_threshold (the reference ranks all of them)")
         metas = example.get("metadata", None) if isinstance(example, dict) else None
         if not metas:
             metas = [None] * B
@@ -417,6 +420,9 @@ class CenterHead(nn.Module):
         counts = num.cpu().tolist()   # the frame's single device->host sync
         if counts[B] & 1:
             self.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+        if counts[B] & 4:
+            self.logger.warning("CenterHead.predict: circle NMS ranked the best 4096 cells of a task; more were above "
+                                "score_threshold (the reference ranks all of them)")
         metas = example.get("metadata", None) if isinstance(example, dict) else None
         if not metas:
             metas = [None] * B

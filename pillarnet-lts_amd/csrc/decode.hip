@@ -242,6 +242,8 @@ __global__ __launch_bounds__(SEL_THREADS) void decode_select_kernel(
   }
   if (tid == 0) { s_cut = 0; s_cnt = 0; s_above = 0; s_incut = 0; s_sub = -1; }
   if (tid == SEL_THREADS - 1 && totals) totals[set] = sfx[tid];   // every candidate of the set
+  // circle NMS ranks every cell above the threshold in the reference; here the best pre_max: say so when that cuts
+  if (tid == SEL_THREADS - 1 && S.nms_thr < 0.f && sfx[tid] > pre_max) atomicOr(&status[0], 4);
   __syncthreads();
   {
     const int above = sfx[tid] - mine;  // keys in bins above this thread's bins

@@ -234,6 +234,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_mask_kernel(
   }
 }
 
+// NW = 64-bit removal words per lane: one wave covers 4096 * NW boxes
+template <int NW>
 __global__ __launch_bounds__(64) void nms_select_kernel(
     const unsigned long long* __restrict__ mask, const int32_t* __restrict__ counts,
     int count_is_host_n, int cap, int col_blocks, const int32_t* __restrict__ post_max_per_set,
@@ -248,12 +250,18 @@ __global__ __launch_bounds__(64) void nms_select_kernel(
   const unsigned long long* M = mask + (size_t)set * cap * col_blocks;
   int32_t* K = keep + (size_t)set * keep_stride;
 
-  unsigned long long remv = 0ull;  // lane c: removal bits of block c
+  unsigned long long remv[NW];  // lane c, word w: removal bits of block w * 64 + c
+#pragma unroll
+  for (int w = 0; w < NW; ++w) remv[w] = 0ull;
   int kept_total = 0;
   for (int b = 0; b < nb && kept_total < post_max; ++b) {
     const int row = b * 64 + lane;
     const unsigned long long diag = row < n ? M[(size_t)row * col_blocks + b] : 0ull;
-    unsigned long long removed = __shfl(remv, b);
+    unsigned long long mine = remv[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+      if ((b >> 6) == w) mine = remv[w];          // wave-uniform pick (no dynamic register index)
+    unsigned long long removed = __shfl(mine, b & 63);
     const int rows_here = n - b * 64;
     if (rows_here < 64) removed |= ~0ull << rows_here;
     unsigned long long kept = 0ull, alive = ~removed;
@@ -268,14 +276,18 @@ __global__ __launch_bounds__(64) void nms_select_kernel(
       if (pos < post_max) K[pos] = row;
     }
     kept_total += __popcll(kept);
-    if (lane > b && lane < nb) {
-      unsigned long long km = kept, acc = 0ull;
-      while (km) {
-        const int j = __builtin_ctzll(km);
-        km &= km - 1ull;
-        acc |= M[(size_t)(b * 64 + j) * col_blocks + lane];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int blk = w * 64 + lane;
+      if (blk > b && blk < nb) {
+        unsigned long long km = kept, acc = 0ull;
+        while (km) {
+          const int j = __builtin_ctzll(km);
+          km &= km - 1ull;
+          acc |= M[(size_t)(b * 64 + j) * col_blocks + blk];
+        }
+        remv[w] |= acc;
       }
-      remv |= acc;
     }
   }
   if (lane == 0) num_keep[set] = kept_total < post_max ? kept_total : post_max;
@@ -313,8 +325,8 @@ extern "C" int pn_nms_rotated(const float* boxes, int num_sets, int cap, const i
                               int32_t* keep, int32_t* num_keep, void* workspace,
                               size_t workspace_bytes, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(num_sets >= 1 && cap >= 1 && cap <= 4096, "pn_nms_rotated: sets %d cap %d (cap <= 4096)",
-               num_sets, cap);
+  PN_CHECK_ARG(num_sets >= 1 && cap >= 1 && cap <= PN_NMS_MAX_BOXES, "pn_nms_rotated: sets %d cap %d (cap <= %d)",
+               num_sets, cap, PN_NMS_MAX_BOXES);
   PN_CHECK_ARG(boxes && keep && num_keep && workspace, "pn_nms_rotated: null argument");
   PN_CHECK_ARG(counts_dev || (count_host >= 1 && count_host <= cap),
                "pn_nms_rotated: need device counts or a host count in 1..cap (got %d)", count_host);
@@ -336,9 +348,14 @@ extern "C" int pn_nms_rotated(const float* boxes, int num_sets, int cap, const i
                      counts_dev, counts_dev ? 0 : count_host, cap, cbk_store, tiles, thresh_dev,
                      thresh, mask);
   PN_CHECK_LAUNCH("nms_mask_kernel");
-  hipLaunchKernelGGL(nms_select_kernel, dim3(num_sets), dim3(64), 0, stream, mask, counts_dev,
-                     counts_dev ? 0 : count_host, cap, cbk_store, post_max_dev, post_max,
-                     keep_stride, keep, num_keep);
+  if (cap <= 4096)
+    hipLaunchKernelGGL(nms_select_kernel<1>, dim3(num_sets), dim3(64), 0, stream, mask, counts_dev,
+                       counts_dev ? 0 : count_host, cap, cbk_store, post_max_dev, post_max,
+                       keep_stride, keep, num_keep);
+  else
+    hipLaunchKernelGGL((nms_select_kernel<PN_NMS_MAX_BOXES / 4096>), dim3(num_sets), dim3(64), 0, stream, mask,
+                       counts_dev, counts_dev ? 0 : count_host, cap, cbk_store, post_max_dev, post_max,
+                       keep_stride, keep, num_keep);
   PN_CHECK_LAUNCH("nms_select_kernel");
   return PN_OK;
 }

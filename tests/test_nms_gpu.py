@@ -45,6 +45,19 @@ def test_nms_dense_cluster_4096(cuda):
     _nms_case(cuda, synth.nms_boxes(4096, seed=7, extent=30.0, cluster=1.0), 0.55)
 
 
+@pytest.mark.parametrize("n", [4097, 5000, 9000])
+def test_nms_beyond_4096_boxes(cuda, n):
+    """the reference's nms_gpu takes any n (iou3d_nms.cpp:113-159); here one wave's removal words cover 16 384."""
+    _nms_case(cuda, synth.nms_boxes(n, seed=11 + n, extent=60.0, cluster=1.2), 0.55)
+
+
+def test_nms_size_limit_is_an_error_not_a_truncation(cuda):
+    from pillarnet_lts_amd import _lib
+    keep = torch.LongTensor(16385)
+    with pytest.raises(_lib.PillarnetHipError, match="16384"):
+        iou3d_nms.nms_gpu_raw(torch.zeros((16385, 7), device=cuda), keep, 0.2)
+
+
 def test_nms_all_identical(cuda):
     b = np.tile(np.array([[1, 2, 0, 4, 2, 1.5, 0.3]], np.float32), (200, 1))
     _nms_case(cuda, b, 0.2)
