@@ -2,7 +2,7 @@
 the points itself, RPNV1 with ds_*/us_* kwargs, CenterHead(in_channels=256, dataset=..., weight=...), geometry in
 test_cfg: the shape of configs/nusc/voxelnet/nusc_centerpoint_pillarnet_rpnv1_h.py, on a reduced range) runs on
 the same HIP path as the live model: with the live model's weights it returns the same detections (bf16: bit for
-bit; fp32: 2e-5, see below)."""
+bit; fp32: the BEV maps within 1e-4, see below)."""
 import logging
 
 import pytest
@@ -68,14 +68,20 @@ def test_legacy_vocabulary_pillarnet_equals_the_live_model(cuda, dtype):
            torch.from_numpy(synth.nusc_sweep(4500, seed=4, r_max=14.0)).to(cuda)]
     ex = {"points": pts, "metadata": [None, None]}
     with torch.no_grad():
+        if dtype == torch.float32:
+            # fp32: the dense part runs torch's library convolutions, which do not promise the same summation
+            # order for two module instances (seen: 4e-6 on a box coordinate), and a difference of that size can
+            # flip an NMS decision -- so the maps are compared, not the detections
+            data = dict(points=ex["points"], batch_size=2)
+            bev_w, _ = live.extract_feat(data)
+            bev_g, _ = old.extract_feat(data)
+            for g, w in zip(bev_g, bev_w):
+                torch.testing.assert_close(g, w, rtol=1e-4, atol=1e-4)
+            return
         want = live(ex, return_loss=False)
         got = old(ex, return_loss=False)
     assert sum(d["scores"].numel() for d in want) > 20
-    for g, w in zip(got, want):
+    for g, w in zip(got, want):                      # bf16: every kernel on the path is this library's and deterministic
         for k in ("box3d_lidar", "scores", "label_preds"):
             assert g[k].shape == w[k].shape, k
-            diff = float((g[k].double() - w[k].double()).abs().max()) if g[k].numel() else 0.0
-            # bf16: every kernel on the path is this library's and deterministic -> identical bits.  fp32: the dense
-            # part runs torch's library convolutions, which do not promise the same summation order for two
-            # module instances (seen: 4e-6 on box coordinates of ~10 m)
-            assert diff == 0.0 if (dtype == torch.bfloat16 or k == "label_preds") else diff <= 2e-5, (k, diff)
+            assert torch.equal(g[k], w[k]), k
