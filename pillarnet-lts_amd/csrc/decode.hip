@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256) void gather_detections_kernel(
     const float* __restrict__ cand_boxes, const float* __restrict__ cand_scores,
     const int32_t* __restrict__ cand_labels, const int32_t* __restrict__ keep,
     const int32_t* __restrict__ num_keep, float* __restrict__ out_boxes,
-    float* __restrict__ out_scores, int64_t* __restrict__ out_labels, int32_t* __restrict__ out_num) {
+    float* __restrict__ out_scores, int64_t* __restrict__ out_labels, int32_t* __restrict__ out_num,
+    const int32_t* __restrict__ status_src, int32_t* __restrict__ status_dst) {
   // one block per (group, sample): every block sums the kept counts of the earlier groups itself (all loads
   // independent), so the groups copy in parallel instead of one after the other
   const int g = blockIdx.x, b = blockIdx.y;
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(256) void gather_detections_kernel(
     out_labels[(size_t)b * out_cap + dst] = cand_labels[(size_t)set * pre_cap + src];
   }
   if (g == 0 && threadIdx.x == 0) out_num[b] = total < out_cap ? total : out_cap;
+  if (g == 0 && b == 0 && threadIdx.x == 0 && status_dst) status_dst[0] = status_src[0];   // (no 4-byte copy launch)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -869,10 +871,8 @@ static int decode_nms_gather(const DecodeSetup& st, int num_groups, int box_dim,
                      box_dim, pre_cap, out_cap, (const float*)(ws + L.cand_boxes),
                      (const float*)(ws + L.cand_scores), (const int32_t*)(ws + L.cand_labels),
                      (const int32_t*)(ws + L.keep), (const int32_t*)(ws + L.num_keep), out_boxes,
-                     out_scores, out_labels, out_num);
+                     out_scores, out_labels, out_num, (const int32_t*)(ws + L.status), status);
   PN_CHECK_LAUNCH("gather_detections_kernel");
-  if (status)
-    PN_CHECK_HIP(hipMemcpyAsync(status, ws + L.status, 4, hipMemcpyDeviceToDevice, stream));
   return PN_OK;
 }
 

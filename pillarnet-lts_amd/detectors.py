@@ -126,6 +126,11 @@ class PillarNet(SingleStageDetector):
     def forward_two_stage(self, example, return_loss=True, **kwargs):
         data = dict(points=example["points"], batch_size=len(example["metadata"]))
         bev_features, backbone_features = self.extract_feat(data)
+        if not return_loss and not kwargs and bev_features[0].dtype == torch.bfloat16:
+            plan = self.bbox_head.lazy_plan(self.test_cfg)    # as in forward(): regression heads at the ranked cells
+            if plan is not None:
+                boxes = self.bbox_head.predict_lazy(example, bev_features, self.test_cfg, plan)
+                return boxes, bev_features, backbone_features, None
         preds = self.bbox_head(bev_features)
         # (the reference's "manual deepcopy"; in inference the packed head output is passed through as is)
         detached = [{k: v.detach() for k, v in p.items()} for p in preds] if return_loss else preds

@@ -55,11 +55,19 @@ void run(float* sink, unsigned long long* cyc) {
 }
 
 // the window kernel's k-step: G MFMAs on G accumulators, R reads requested at the top, one wait per k-step
-template <int NWAVES, int G, int R>
+template <int NWAVES, int G, int R, int RANDOM = 0>
 __global__ __launch_bounds__(NWAVES * 64) void kstep(int iters, float* sink, unsigned long long* cyc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < 16384; i += NWAVES * 64) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 127);
+  for (int i = tid; i < 16384; i += NWAVES * 64) {
+    if (RANDOM) {   // two random bf16 per dword, magnitudes in [2^-8, 2^-7): the operands' bits toggle like real data
+      unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      const unsigned lo = (h & 0x807fu) | 0x3b80u, hi = ((h >> 16) & 0x807fu) | 0x3b80u;
+      reinterpret_cast<unsigned*>(smem)[i] = lo | (hi << 16);
+    } else {
+      reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 127);
+    }
+  }
   __syncthreads();
   f32x16 acc[G];
   for (int i = 0; i < G; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
@@ -87,22 +95,22 @@ __global__ __launch_bounds__(NWAVES * 64) void kstep(int iters, float* sink, uns
   if (s == 12345.f) sink[0] = s;
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
-template <int NWAVES, int G, int R>
+template <int NWAVES, int G, int R, int RANDOM = 0>
 void runk(float* sink, unsigned long long* cyc) {
   const int iters = 2000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
-  hipFuncSetAttribute((const void*)kstep<NWAVES, G, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)kstep<NWAVES, G, R, RANDOM>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((kstep<NWAVES, G, R>), dim3(256), dim3(NWAVES * 64), 65536, 0, iters, sink, cyc);
+    hipLaunchKernelGGL((kstep<NWAVES, G, R, RANDOM>), dim3(256), dim3(NWAVES * 64), 65536, 0, iters, sink, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
   unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
   const double n = iters * 2.0 * G;
-  printf("kstep: waves/CU %2d  %d MFMA + %d ds_read_b128 per k-step : %5.1f ticks/MFMA/wave  %5.2f ns/MFMA/SIMD  (%.0f TF/s chip)\n",
-         NWAVES, G, R, (double)c / n, ms * 1e6 / n / (NWAVES / 4.0), 256.0 * NWAVES * n * 32768.0 / (ms * 1e-3) / 1e12);
+  printf("kstep%s: waves/CU %2d  %d MFMA + %d ds_read_b128 per k-step : %5.1f ticks/MFMA/wave  %5.2f ns/MFMA/SIMD  (%.0f TF/s chip)\n",
+         RANDOM ? " (random operands)" : "", NWAVES, G, R, (double)c / n, ms * 1e6 / n / (NWAVES / 4.0), 256.0 * NWAVES * n * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -117,5 +125,6 @@ int main() {
   runk<4, 4, 0>(sink, cyc); runk<4, 4, 4>(sink, cyc); runk<8, 4, 0>(sink, cyc); runk<8, 4, 4>(sink, cyc);
   runk<8, 4, 2>(sink, cyc); runk<4, 8, 6>(sink, cyc); runk<8, 8, 6>(sink, cyc); runk<4, 8, 4>(sink, cyc);
   runk<8, 8, 0>(sink, cyc);
+  runk<4, 4, 0, 1>(sink, cyc); runk<8, 4, 0, 1>(sink, cyc); runk<8, 4, 4, 1>(sink, cyc); runk<4, 8, 6, 1>(sink, cyc); runk<8, 8, 6, 1>(sink, cyc);
   return 0;
 }
