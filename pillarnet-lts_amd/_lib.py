@@ -9,6 +9,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpillarnet_hip.so")
+LIB_PATH = os.environ.get("PN_LIB_PATH", LIB_PATH)   # tuning: A/B two builds inside one GPU job
 
 PN_MAX_BATCH = 32
 PN_DTYPE_F32, PN_DTYPE_BF16 = 0, 1
