@@ -115,6 +115,11 @@ int pn_nms_rotated(const float* boxes, int num_sets, int cap, const int32_t* cou
                    const int32_t* post_max_dev, int post_max, int keep_stride,
                    int32_t* keep, int32_t* num_keep, void* workspace,
                    size_t workspace_bytes, pnStream stream);
+/* iou3d_nms_cuda.nms_normal_gpu (det3d/ops/iou3d_nms/src/iou3d_nms_api.cpp:16, iou3d_nms.cpp:162-215,
+ * nms_normal_kernel iou3d_nms_kernel.cu:327-385): greedy NMS on the axis-aligned BEV IoU of boxes [n, 7] sorted by
+ * score (heading ignored); keep [post_max] int32 positions, ascending; workspace: pn_nms_workspace_bytes(1, n). */
+int pn_nms_normal(const float* boxes, int n, float thresh, int post_max, int32_t* keep, int32_t* num_keep,
+                  void* workspace, size_t workspace_bytes, pnStream stream);
 
 /* pn_nms_rotated without the workspace argument, for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no

@@ -56,6 +56,7 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_size_t, POINTER(c_void_p),
                              POINTER(c_void_p), c_void_p]),
     "pn_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pn_nms_normal": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_nms_rotated": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_float,
                                c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),

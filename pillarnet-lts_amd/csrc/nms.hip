@@ -495,6 +495,47 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
   }
 }
 
+// nms_normal_kernel (iou3d_nms_kernel.cu:327-385): axis-aligned BEV IoU (the heading is ignored), same tiling as
+// the rotated mask; every pair is a dozen flops, so no compaction passes
+__global__ __launch_bounds__(NMS_THREADS) void nms_normal_mask_kernel(const float* __restrict__ boxes, int n, int col_blocks,
+                                                                      float thr, unsigned long long* __restrict__ mask) {
+  __shared__ float rowb[NMS_TILE][5], colb[NMS_TILE][5];     // x, y, dx, dy (+1: bank spread)
+  __shared__ unsigned long long lmask[NMS_TILE];
+  int tile = blockIdx.x, rb = 0, rem = col_blocks;
+  while (tile >= rem) { tile -= rem; ++rb; --rem; }
+  const int cb = rb + tile, tid = threadIdx.x;
+  if (tid < 2 * NMS_TILE) {
+    const bool col = tid >= NMS_TILE;
+    const int l = tid & (NMS_TILE - 1), g = (col ? cb : rb) * NMS_TILE + l;
+    float* d = col ? colb[l] : rowb[l];
+    if (g < n) {
+      const float* b = boxes + (size_t)g * 7;
+      d[0] = b[0]; d[1] = b[1]; d[2] = b[3]; d[3] = b[4];
+    }
+    if (!col) lmask[l] = 0ull;
+  }
+  __syncthreads();
+  const int r = tid & 63, c0 = (tid >> 6) * 16, gr = rb * NMS_TILE + r;
+  unsigned long long bits = 0ull;
+  if (gr < n) {
+    const float ax = rowb[r][0], ay = rowb[r][1], adx = rowb[r][2], ady = rowb[r][3];
+    for (int k = 0; k < 16; ++k) {
+      const int c = c0 + k, gc = cb * NMS_TILE + c;
+      if (gc < n && gc > gr) {
+        const float bx = colb[c][0], by = colb[c][1], bdx = colb[c][2], bdy = colb[c][3];
+        const float left = fmaxf(ax - adx / 2, bx - bdx / 2), right = fminf(ax + adx / 2, bx + bdx / 2);
+        const float top = fmaxf(ay - ady / 2, by - bdy / 2), bottom = fminf(ay + ady / 2, by + bdy / 2);
+        const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+        const float inter = width * height;
+        if (inter / fmaxf(adx * ady + bdx * bdy - inter, IOU_EPS) > thr) bits |= 1ull << c;
+      }
+    }
+  }
+  if (bits) atomicOr(&lmask[r], bits);
+  __syncthreads();
+  if (tid < NMS_TILE && rb * NMS_TILE + tid < n) mask[(size_t)(rb * NMS_TILE + tid) * col_blocks + cb] = lmask[tid];
+}
+
 static size_t nms_mask_bytes(int num_sets, int cap) {
   const size_t cbk = (size_t)(cap + 63) / 64;
   return pn_align_up((size_t)num_sets * cap * cbk * 8, 256);
@@ -571,6 +612,30 @@ extern "C" int pn_nms_rotated(const float* boxes, int num_sets, int cap, const i
                               size_t workspace_bytes, pnStream stream_) {
   return nms_run(boxes, num_sets, cap, counts_dev, count_host, thresh_dev, thresh, post_max_dev, post_max,
                  keep_stride, keep, num_keep, workspace, workspace_bytes, true, (hipStream_t)stream_);
+}
+
+extern "C" int pn_nms_normal(const float* boxes, int n, float thresh, int post_max, int32_t* keep, int32_t* num_keep,
+                             void* workspace, size_t workspace_bytes, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(boxes && keep && num_keep && workspace && n >= 1 && n <= PN_NMS_MAX_BOXES && post_max >= 1,
+               "pn_nms_normal: bad argument (n %d, at most %d)", n, PN_NMS_MAX_BOXES);
+  if (workspace_bytes < nms_mask_bytes(1, n)) {
+    pn_set_error("pn_nms_normal: workspace %zu < %zu bytes", workspace_bytes, nms_mask_bytes(1, n));
+    return PN_ENOSPC;
+  }
+  const int cbk = (n + 63) / 64;
+  unsigned long long* mask = (unsigned long long*)workspace;
+  hipLaunchKernelGGL(nms_normal_mask_kernel, dim3(cbk * (cbk + 1) / 2), dim3(NMS_THREADS), 0, stream, boxes, n, cbk, thresh,
+                     mask);
+  PN_CHECK_LAUNCH("nms_normal_mask_kernel");
+  if (n <= 4096)
+    hipLaunchKernelGGL(nms_select_kernel<1>, dim3(1), dim3(64), 0, stream, mask, nullptr, n, n, cbk, nullptr, post_max, post_max,
+                       keep, num_keep);
+  else
+    hipLaunchKernelGGL((nms_select_kernel<PN_NMS_MAX_BOXES / 4096>), dim3(1), dim3(64), 0, stream, mask, nullptr, n, n, cbk,
+                       nullptr, post_max, post_max, keep, num_keep);
+  PN_CHECK_LAUNCH("nms_select_kernel");
+  return PN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

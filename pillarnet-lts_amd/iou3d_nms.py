@@ -122,3 +122,33 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
     keep = torch.LongTensor(boxes.size(0))
     num_out = nms_gpu_raw(boxes, keep, thresh)
     return order[keep[:num_out].to(boxes.device)].contiguous(), None
+
+
+def nms_normal_gpu_raw(boxes, keep, thresh):
+    """`iou3d_nms_cuda.nms_normal_gpu(boxes, keep, thresh) -> num_kept` (iou3d_nms.cpp:162-215)."""
+    _need_cuda(boxes, "nms_normal_gpu")
+    n = boxes.shape[0]
+    if n == 0:
+        return 0
+    boxes = boxes.contiguous().float()
+    L = _lib.lib()
+    dev = boxes.device
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    num = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(L.pn_nms_workspace_bytes(1, n)), dtype=torch.uint8, device=dev)
+    rc = L.pn_nms_normal(_lib.ptr(boxes), n, float(thresh), n, _lib.ptr(out), _lib.ptr(num), _lib.ptr(ws), ws.numel(),
+                         _lib.current_stream(dev))
+    _lib.check(rc, "pn_nms_normal")
+    m = int(num.item())
+    keep[:m] = out[:m].to("cpu", torch.int64)
+    return m
+
+
+def nms_normal_gpu(boxes, scores, thresh, **kwargs):
+    """iou3d_nms_utils.py:136-151."""
+    assert boxes.shape[1] == 7
+    order = scores.sort(0, descending=True)[1]
+    boxes = boxes[order].contiguous()
+    keep = torch.LongTensor(boxes.size(0))
+    num_out = nms_normal_gpu_raw(boxes, keep, thresh)
+    return order[keep[:num_out].to(boxes.device)].contiguous(), None

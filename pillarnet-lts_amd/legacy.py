@@ -15,8 +15,8 @@ the upstream CenterPoint conventions and is NUMERICALLY UNPINNED:
     CenterPoint defines it (dense pillars from the hard voxelizer), in torch;
   * VoxelNet's 3-D sparse backbone (SpMiddleResNetFHD) constructs but raises on forward: 3-D sparse
     convolution is outside this package's 2-D pillar hot path;
-  * TwoStageDetector / BEVFeatureExtractor / RoIHead follow det3d/models/detectors/two_stage.py:10-41,
-    second_stage/bird_eye_view.py:10-41 and roi_heads/roi_head.py:14-111.
+  * TwoStageDetector / BEVFeatureExtractor / RoIHead follow det3d/models/detectors/two_stage.py:10-195,
+    second_stage/bird_eye_view.py:10-41 and roi_heads/roi_head.py:14-111 (inference; the training branch raises).
 Pipeline step `Voxelization` = the hard voxelizer (det3d/ops/point_cloud/point_cloud_ops.py:112-184), here as a
 host-side C routine in the library (`pn_points_to_voxel`); legacy `voxel_generator` dicts
 (configs/nusc/voxelnet/nusc_centerpoint_pillarnet_h.py:151-158).
@@ -298,6 +298,21 @@ class PointPillars(SingleStageDetector):
         return self.bbox_head.predict(example, preds, self.test_cfg)
 
 
+    def forward_two_stage(self, example, return_loss=True, **kwargs):
+        """upstream CenterPoint point_pillars.py forward_two_stage: (boxes, BEV feature map, loss)."""
+        data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
+                    batch_size=len(example["num_voxels"]), input_shape=example["shape"][0])
+        x = self.extract_feat(data)
+        if isinstance(x, tuple) and x[0].dim() == 3:
+            x = torch.stack(x)
+        bev = x[0] if isinstance(x, (list, tuple)) else x
+        preds = self.bbox_head((bev,))
+        detached = [{k: v.detach() for k, v in p.items()} for p in preds]
+        boxes = self.bbox_head.predict(example, detached, self.test_cfg)
+        loss = self.bbox_head.loss(example, preds, self.train_cfg) if return_loss else None
+        return boxes, bev, loss
+
+
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
     """det3d/models/detectors/voxelnet.py:6-57 (its backbone here raises on forward, see SpMiddleResNetFHD)."""
@@ -317,6 +332,21 @@ class VoxelNet(SingleStageDetector):
         return self.bbox_head.predict(example, preds, self.test_cfg)
 
 
+def bilinear_interpolate_torch(im, x, y):
+    """det3d/core/utils/center_utils.py:91-120: im [H, W, C], x / y [N] in cell units; corners clamped to the map, weights
+    from the clamped corners (so points beyond the edge fade out exactly as in the reference)."""
+    x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = torch.clamp(x0, 0, im.shape[1] - 1), torch.clamp(x1, 0, im.shape[1] - 1)
+    y0, y1 = torch.clamp(y0, 0, im.shape[0] - 1), torch.clamp(y1, 0, im.shape[0] - 1)
+    wa = (x1.type_as(x) - x) * (y1.type_as(y) - y)
+    wb = (x1.type_as(x) - x) * (y - y0.type_as(y))
+    wc = (x - x0.type_as(x)) * (y1.type_as(y) - y)
+    wd = (x - x0.type_as(x)) * (y - y0.type_as(y))
+    return (im[y0, x0] * wa.unsqueeze(1) + im[y1, x0] * wb.unsqueeze(1) + im[y0, x1] * wc.unsqueeze(1) +
+            im[y1, x1] * wd.unsqueeze(1))
+
+
 @SECOND_STAGE.register_module
 class BEVFeatureExtractor(nn.Module):
     """det3d/models/second_stage/bird_eye_view.py:10-41: bilinear BEV features at the box centre points."""
@@ -331,7 +361,6 @@ class BEVFeatureExtractor(nn.Module):
         return a1, a2
 
     def forward(self, example, batch_centers, num_point):
-        from .second_stage import bilinear_interpolate_torch
         out = []
         for b in range(len(example["bev_feature"])):
             xs, ys = self.absl_to_relative(batch_centers[b])
@@ -396,19 +425,28 @@ class RoIHead(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, batch_dict, training=True):
+        """roi_head.py:70-111, inference branch."""
         if training:
             raise NotImplementedError("legacy RoIHead: training targets are built for RoIMIXHead only")
+        from .second_stage import RoIMIXHead
+        batch_dict["batch_size"] = len(batch_dict["rois"])
+        if self.add_box_param:
+            batch_dict["roi_features"] = torch.cat([batch_dict["roi_features"], batch_dict["rois"],
+                                                    batch_dict["roi_scores"].unsqueeze(-1)], dim=-1)
         feats = batch_dict["roi_features"].reshape(-1, 1, batch_dict["roi_features"].shape[-1]).permute(0, 2, 1).contiguous()
         shared = self.shared_fc_layer(feats)
-        batch_dict["batch_cls_preds"] = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
-        batch_dict["batch_box_preds"] = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        cls, boxes = RoIMIXHead.generate_predicted_boxes(self, batch_dict["batch_size"], batch_dict["rois"], rcnn_cls, rcnn_reg)
+        batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"] = cls, boxes
+        batch_dict["cls_preds_normalized"] = False
         return batch_dict
 
 
 @DETECTORS.register_module
 class TwoStageDetector(BaseDetector):
-    """det3d/models/detectors/two_stage.py:10-41 (construction; the legacy first stages it wraps are the
-    adapters above)."""
+    """det3d/models/detectors/two_stage.py:10-195, inference path (the legacy first stages it wraps are the
+    adapters above; their numerics are unpinned, see the module docstring)."""
 
     def __init__(self, first_stage_cfg, second_stage_modules, roi_head, point_head=None, num_point=1, freeze=False,
                  use_final_feature=False, NMS_POST_MAXSIZE=None, **kwargs):
@@ -427,9 +465,77 @@ class TwoStageDetector(BaseDetector):
         self.roi_head = builder.build(roi_head, ROI_HEAD)
         self.num_point, self.use_final_feature = num_point, use_final_feature
 
+    def get_box_center(self, boxes):
+        """two_stage.py:52-79: the box centre, or centre + the four face centres of the BEV box (num_point 5)."""
+        centers = []
+        for box in boxes:
+            b = box["box3d_lidar"]
+            if self.num_point == 1 or len(b) == 0:
+                centers.append(b[:, :3])
+            elif self.num_point == 5:
+                c2, h, d2, ry = b[:, :2], b[:, 2:3], b[:, 3:5], b[:, -1]
+                # box_torch_ops.center_to_corner_box2d (det3d/core/bbox/box_torch_ops.py:198-217): corners clockwise
+                # from the minimum point, rotated clockwise by ry
+                norm = b.new_tensor([[-0.5, -0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5]])
+                corners = d2.view(-1, 1, 2) * norm.view(1, 4, 2)
+                sin, cos = torch.sin(ry).view(-1, 1), torch.cos(ry).view(-1, 1)
+                corners = torch.stack([corners[..., 0] * cos + corners[..., 1] * sin,
+                                       -corners[..., 0] * sin + corners[..., 1] * cos], dim=-1) + c2.view(-1, 1, 2)
+                mid = lambda i, j: torch.cat([(corners[:, i] + corners[:, j]) / 2, h], dim=-1)
+                centers.append(torch.cat([b[:, :3], mid(0, 1), mid(2, 3), mid(0, 3), mid(1, 2)], dim=0))
+            else:
+                raise NotImplementedError()
+        return centers
+
+    def reorder_first_stage_pred_and_feature(self, first_pred, example, features):
+        """two_stage.py:81-118: pad every sample to NMS_POST_MAXSIZE RoIs, labels shifted by +1."""
+        B, L, N = len(first_pred), first_pred[0]["box3d_lidar"].shape[1], self.NMS_POST_MAXSIZE
+        F = sum(feat[0].shape[-1] for feat in features)
+        ref = first_pred[0]["box3d_lidar"]
+        rois, scores = ref.new_zeros((B, N, L)), first_pred[0]["scores"].new_zeros((B, N))
+        labels = first_pred[0]["label_preds"].new_zeros((B, N), dtype=torch.long)
+        feats = features[0][0].new_zeros((B, N, F))
+        for i in range(B):
+            n = features[0][i].shape[0]
+            box = first_pred[i]["box3d_lidar"]
+            if self.roi_head.code_size == 9:
+                box = box[:, [0, 1, 2, 3, 4, 5, 8, 6, 7]]
+            rois[i, :n], labels[i, :n], scores[i, :n] = box, first_pred[i]["label_preds"] + 1, first_pred[i]["scores"]
+            feats[i, :n] = torch.cat([feat[i] for feat in features], dim=-1)
+        example.update(rois=rois, roi_labels=labels, roi_scores=scores, roi_features=feats, has_class_labels=True)
+        return example
+
+    def post_process(self, batch_dict):
+        """two_stage.py:120-150: score = sqrt(sigmoid(cls) * first-stage score), padded RoIs dropped, no second NMS."""
+        out = []
+        for i in range(batch_dict["batch_size"]):
+            box, cls, lab = batch_dict["batch_box_preds"][i], batch_dict["batch_cls_preds"][i], batch_dict["roi_labels"][i]
+            if box.shape[-1] == 9:
+                box = box[:, [0, 1, 2, 3, 4, 5, 7, 8, 6]]
+            score = torch.sqrt(torch.sigmoid(cls).view(-1) * batch_dict["roi_scores"][i].view(-1))
+            mask = (lab != 0).view(-1)
+            out.append({"box3d_lidar": box[mask], "scores": score[mask], "label_preds": lab[mask] - 1,
+                        "metadata": batch_dict["metadata"][i]})
+        return out
+
     def forward(self, example, return_loss=True, **kwargs):
-        raise NotImplementedError("legacy TwoStageDetector: only construction is provided; PillarRCNN is the live "
-                                  "two-stage detector")
+        """two_stage.py:152-195, inference (the second-stage training targets of the legacy RoIHead are not built)."""
+        if return_loss:
+            raise NotImplementedError("legacy TwoStageDetector: inference only; PillarRCNN is the live two-stage detector")
+        out = self.single_det.forward_two_stage(example, return_loss, **kwargs)
+        if len(out) == 5:
+            first, bev, example["voxel_feature"], final, _ = out
+        elif len(out) == 3:
+            first, bev, _ = out
+            final = None
+        else:
+            raise NotImplementedError
+        src = final if self.use_final_feature else bev
+        example["bev_feature"] = src.permute(0, 2, 3, 1).contiguous()
+        centers = self.get_box_center(first)
+        features = [m.forward(example, centers, self.num_point) for m in self.second_stage]
+        example = self.reorder_first_stage_pred_and_feature(first, example, features)
+        return self.post_process(self.roi_head(example, training=False))
 
 
 # ---- pipeline: the hard voxelizer -----------------------------------------------------------------------------

@@ -85,3 +85,71 @@ def test_legacy_vocabulary_pillarnet_equals_the_live_model(cuda, dtype):
         for k in ("box3d_lidar", "scores", "label_preds"):
             assert g[k].shape == w[k].shape, k
             assert torch.equal(g[k], w[k]), k
+
+
+def test_legacy_two_stage_pointpillars_runs_end_to_end(cuda):
+    """TwoStageDetector(PointPillars first stage, BEVFeatureExtractor with five points per box, RoIHead) in the legacy
+    vocabulary (the shape of configs/waymo/pp/two_stage/*.py, small range): voxelise on the host, detect, refine.
+    No reference implementation of these types exists, so this checks the contract: every first-stage box comes
+    back once, refined, with label, a score in (0, 1] and finite coordinates; bilinear_interpolate_torch against
+    a direct evaluation."""
+    import numpy as np
+    from pillarnet_lts_amd import legacy
+    tasks = [dict(num_class=3, class_names=["VEHICLE", "PEDESTRIAN", "CYCLIST"])]
+    first = dict(
+        type="PointPillars", pretrained=None,
+        reader=dict(type="PillarFeatureNet", num_filters=[64, 64], num_input_features=5, with_distance=False,
+                    voxel_size=(0.32, 0.32, 6.0), pc_range=(-20.48, -20.48, -2, 20.48, 20.48, 4.0)),
+        backbone=dict(type="PointPillarsScatter", ds_factor=1),
+        neck=dict(type="RPN", layer_nums=[3, 5, 5], ds_layer_strides=[1, 2, 2], ds_num_filters=[64, 128, 256],
+                  us_layer_strides=[1, 2, 4], us_num_filters=[128, 128, 128], num_input_features=64,
+                  logger=logging.getLogger("RPN")),
+        bbox_head=dict(type="CenterHead", in_channels=128 * 3, tasks=tasks, dataset="waymo", weight=2,
+                       code_weights=[1.0] * 8,
+                       common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2)}))
+    model_cfg = dict(CLASS_AGNOSTIC=True, SHARED_FC=[256, 256], CLS_FC=[256, 256], REG_FC=[256, 256], DP_RATIO=0.3)
+    cfg = dict(type="TwoStageDetector", first_stage_cfg=first,
+               second_stage_modules=[dict(type="BEVFeatureExtractor", pc_start=[-20.48, -20.48], voxel_size=[0.32, 0.32],
+                                          out_stride=1)],
+               roi_head=dict(type="RoIHead", input_channels=128 * 3 * 5, model_cfg=model_cfg, code_size=7),
+               NMS_POST_MAXSIZE=100, num_point=5, freeze=True)
+    test_cfg = P.ConfigDict(post_center_limit_range=[-25, -25, -10.0, 25, 25, 10.0], max_per_img=500,
+                            nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=500,
+                                     nms_post_max_size=100, nms_iou_threshold=0.7),
+                            score_threshold=0.1, rectifier=0, pc_range=[-20.48, -20.48], out_size_factor=1,
+                            voxel_size=[0.32, 0.32])
+    torch.manual_seed(0)
+    model = P.build_detector(cfg, train_cfg=None, test_cfg=test_cfg).to(cuda).eval()
+    with torch.no_grad():
+        model.single_det.bbox_head.task_heads[0].hm[-1].weight.mul_(8.0)
+    step = legacy.Voxelization(cfg=dict(range=[-20.48, -20.48, -2, 20.48, 20.48, 4.0], voxel_size=[0.32, 0.32, 6.0],
+                                        max_points_in_voxel=20, max_voxel_num=[8000, 8000]))
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.uniform(-20, 20, (9000, 2)), rng.uniform(-1.5, 3, (9000, 1)), rng.random((9000, 2))],
+                         axis=1).astype(np.float32)
+    res, _ = step({"mode": "val", "lidar": {"points": pts}}, {})
+    vox = res["lidar"]["voxels"]
+    batch = P.collate_kitti([dict(metadata={"token": 0}, points=pts, voxels=vox["voxels"], shape=vox["shape"],
+                                  num_points=vox["num_points"], num_voxels=vox["num_voxels"],
+                                  coordinates=vox["coordinates"])])
+    ex = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        first_boxes, bev, _ = model.single_det.forward_two_stage(dict(ex), return_loss=False)
+        out = model(dict(ex), return_loss=False)
+    n = first_boxes[0]["box3d_lidar"].shape[0]
+    assert 0 < n <= 100 and bev.shape == (1, 384, 128, 128)
+    d = out[0]
+    assert d["box3d_lidar"].shape == (n, 7) and torch.isfinite(d["box3d_lidar"]).all()
+    assert torch.equal(d["label_preds"], first_boxes[0]["label_preds"])
+    assert (d["scores"] > 0).all() and (d["scores"] <= 1).all()
+    assert float((d["box3d_lidar"] - first_boxes[0]["box3d_lidar"]).abs().max()) > 0          # refined
+    # the interpolation helper against a direct evaluation at interior points
+    im = torch.rand(7, 9, 3, device=cuda)
+    x, y = torch.tensor([1.25, 7.5, 0.0], device=cuda), torch.tensor([2.5, 0.75, 5.0], device=cuda)
+    got = legacy.bilinear_interpolate_torch(im, x, y)
+    for k in range(3):
+        x0, y0 = int(x[k]), int(y[k])
+        fx, fy = float(x[k]) - x0, float(y[k]) - y0
+        want = (im[y0, x0] * (1 - fx) * (1 - fy) + im[y0 + 1, x0] * (1 - fx) * fy + im[y0, x0 + 1] * fx * (1 - fy) +
+                im[y0 + 1, x0 + 1] * fx * fy)
+        torch.testing.assert_close(got[k], want, rtol=1e-5, atol=1e-6)

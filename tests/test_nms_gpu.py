@@ -123,3 +123,27 @@ def test_nms_properties_full_size(cuda):
     dropped = np.setdiff1d(np.arange(1000), k)
     for d in dropped:
         assert (iou[k[k < d], d] > 0.2).any()
+
+
+@pytest.mark.parametrize("n", [1, 65, 700, 5000])
+def test_nms_normal_matches_the_reference_definition(cuda, n):
+    """nms_normal_gpu (iou3d_nms.cpp:162-215): greedy NMS on the axis-aligned IoU of iou3d_nms_kernel.cu:327-338,
+    restated here in float32 numpy (same operation order: the keep lists must be equal)."""
+    b = synth.nms_boxes(n, seed=90 + n, extent=40.0, cluster=1.5)
+    scores = np.linspace(1.0, 0.0, n).astype(np.float32)      # already sorted
+    f = np.float32
+    x1, x2 = b[:, 0] - b[:, 3] / f(2), b[:, 0] + b[:, 3] / f(2)
+    y1, y2 = b[:, 1] - b[:, 4] / f(2), b[:, 1] + b[:, 4] / f(2)
+    area = b[:, 3] * b[:, 4]
+    alive, want = np.ones(n, bool), []
+    for i in range(n):
+        if not alive[i]:
+            continue
+        want.append(i)
+        w = np.maximum(np.minimum(x2[i], x2) - np.maximum(x1[i], x1), f(0))
+        h = np.maximum(np.minimum(y2[i], y2) - np.maximum(y1[i], y1), f(0))
+        inter = w * h
+        iou = inter / np.maximum(area[i] + area - inter, f(1e-8))
+        alive[(iou > f(0.3)) & (np.arange(n) > i)] = False
+    got, _ = iou3d_nms.nms_normal_gpu(torch.from_numpy(b).to(cuda), torch.from_numpy(scores).to(cuda), 0.3)
+    np.testing.assert_array_equal(got.cpu().numpy(), np.asarray(want))
