@@ -12,3 +12,4 @@ from .checkpoint import (load_checkpoint, load_state_dict, resume, save_checkpoi
                          save_epoch_checkpoint)
 from .wire import collate_kitti  # noqa: F401
 from . import solver, wire  # noqa: F401
+from .frame_graph import FrameGraphs  # noqa: F401

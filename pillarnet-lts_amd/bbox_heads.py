@@ -233,13 +233,16 @@ class CenterHead(nn.Module):
     LAZY_MAX_CELLS = 262144     # pn_centerhead_select keeps a bit per map cell in LDS
 
     @torch.no_grad()
-    def predict_lazy(self, example, x, test_cfg, plan, **kwargs):
+    def predict_lazy(self, example, x, test_cfg, plan, deferred=False, raw=False, **kwargs):
         """forward + predict in one: heat maps densely, cells ranked, regression heads at the ranked cells
         only.  Same outputs as `predict(example, self(x), test_cfg)`; falls back to exactly that when the
-        library reports that the centre-range mask would have changed the ranking (status bit 1)."""
+        library reports that the centre-range mask would have changed the ranking (status bit 2).
+        deferred=True returns a `PendingDetections` whose result() does the frame's host sync; raw=True returns
+        the fixed-capacity (boxes, scores, labels, counts + status) tensors with no host sync at all (None when
+        the maps are too large for the ranked path)."""
         from . import dense_hip
         if any(f.shape[2] * f.shape[3] > self.LAZY_MAX_CELLS for f in x):
-            return self.predict(example, self(x), test_cfg, **kwargs)
+            return None if raw else self.predict(example, self(x), test_cfg, **kwargs)
         feats = [dense_hip.Rows.from_nchw(f) for f in x]
         dense = plan.run_hm(feats)
         nms_cfg = test_cfg["nms"]
@@ -322,19 +325,11 @@ class CenterHead(nn.Module):
                                              _lib.ptr(labels), _lib.ptr(num), ctypes.c_void_p(num.data_ptr() + 4 * B),
                                              _lib.ptr(ws), wsb, st)
         _lib.check(rc, "pn_centerhead_detect_selected")
-        counts = num.cpu().tolist()       # the frame's single device->host sync
-        if counts[B] & 2:                 # the range mask removed ranked cells of an over-full set: dense redo
-            return self.predict(example, self(x), test_cfg, **kwargs)
-        if counts[B] & 1:
-            self.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
-        if counts[B] & 4:
-            self.logger.warning("CenterHead.predict: circle NMS ranked the best 4096 cells of a task; more were above "
-                                "score_threshold (the reference ranks all of them)")
-        metas = example.get("metadata", None) if isinstance(example, dict) else None
-        if not metas:
-            metas = [None] * B
-        return [{"box3d_lidar": boxes[b, :counts[b]], "scores": scores[b, :counts[b]],
-                 "label_preds": labels[b, :counts[b]], "metadata": metas[b]} for b in range(B)]
+        if raw:
+            return boxes, scores, labels, num
+        pending = PendingDetections(self, example, (boxes, scores, labels, num),
+                                    lambda: self.predict(example, self(x), test_cfg, **kwargs))
+        return pending if deferred else pending.result()
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
@@ -432,6 +427,56 @@ class CenterHead(nn.Module):
             out.append({"box3d_lidar": boxes[b, :n], "scores": scores[b, :n],
                         "label_preds": labels[b, :n], "metadata": metas[b]})
         return out
+
+
+class PendingDetections:
+    """Detections of a frame whose kernels are queued but not waited for.
+
+    The per-sample counts travel to pinned host memory behind the frame's last kernel and an event marks
+    that copy; result() waits for the event alone, so a caller may queue the next frame before it asks for
+    this one and the GPU never idles through the host's hand-over between frames."""
+
+    def __init__(self, head, example, tensors, redo):
+        self.head, self.example, self.redo = head, example, redo     # redo(): the frame again on the dense path
+        self.boxes, self.scores, self.labels, num = tensors
+        self.host = torch.empty(num.shape, dtype=num.dtype, pin_memory=True)
+        self.host.copy_(num, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.out = None
+
+    def result(self):
+        if self.out is not None:
+            return self.out
+        self.event.synchronize()          # the frame's single device->host sync
+        head, example = self.head, self.example
+        B = self.boxes.shape[0]
+        counts = self.host.tolist()
+        if counts[B] & 2:                 # the range mask removed ranked cells of an over-full set: dense redo
+            self.out, self.redo = self.redo(), None
+            return self.out
+        if counts[B] & 1:
+            head.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+        if counts[B] & 4:
+            head.logger.warning("CenterHead.predict: circle NMS ranked the best 4096 cells of a task; more were above "
+                                "score_threshold (the reference ranks all of them)")
+        metas = example.get("metadata", None) if isinstance(example, dict) else None
+        if not metas:
+            metas = [None] * B
+        self.out = [{"box3d_lidar": self.boxes[b, :counts[b]], "scores": self.scores[b, :counts[b]],
+                     "label_preds": self.labels[b, :counts[b]], "metadata": metas[b]} for b in range(B)]
+        self.redo = None
+        return self.out
+
+
+class ReadyDetections:
+    """a finished result behind the PendingDetections interface (paths that sync inside the call)."""
+
+    def __init__(self, out):
+        self.out = out
+
+    def result(self):
+        return self.out
 
 
 def resolve_legacy_geometry(head, test_cfg):

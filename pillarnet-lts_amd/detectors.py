@@ -123,6 +123,21 @@ class PillarNet(SingleStageDetector):
             return self.bbox_head.loss(example, preds, self.train_cfg)
         return self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)
 
+    @torch.no_grad()
+    def forward_deferred(self, example):
+        """inference with the frame's host sync postponed: queues the frame's kernels and returns a handle
+        whose result() waits for this frame only and returns what forward(example, return_loss=False) does.
+        A loop that queues frame i+1 before it takes frame i's result keeps the GPU busy while the host
+        hands a frame over (dist_test.py's loop waits per batch)."""
+        from .bbox_heads import ReadyDetections
+        data = dict(points=example["points"], batch_size=len(example["metadata"]))
+        bev_features, _ = self.extract_feat(data)
+        plan = self.bbox_head.lazy_plan(self.test_cfg) if bev_features[0].dtype == torch.bfloat16 else None
+        if plan is not None:
+            out = self.bbox_head.predict_lazy(example, bev_features, self.test_cfg, plan, deferred=True)
+            return out if hasattr(out, "result") else ReadyDetections(out)
+        return ReadyDetections(self.bbox_head.predict(example, self.bbox_head(bev_features), self.test_cfg))
+
     def forward_two_stage(self, example, return_loss=True, **kwargs):
         data = dict(points=example["points"], batch_size=len(example["metadata"]))
         bev_features, backbone_features = self.extract_feat(data)

@@ -1,0 +1,93 @@
+"""One HIP graph per frame shape for PillarNet inference.
+
+A nuScenes frame is ~75 kernel launches of 2..50 us each; queued from Python one by one they cost the host about as
+long as they cost the GPU.  Every launch of the inference path is sized by capacities known on the host (point
+count, grid size) and reads the live counts from device memory, so a frame with the same padded point counts is
+the same launch sequence with the same arguments: it is captured once and replayed.
+
+Points are copied into the graph's input buffer and padded to a multiple of `bucket` with points far outside the
+range, which the reader's first pass drops exactly as it drops a real out-of-range point
+(det3d/models/readers/dynamic_pillar_encoder.py:30-41 masks them the same way).
+"""
+from collections import OrderedDict
+
+import torch
+
+from .bbox_heads import PendingDetections, ReadyDetections
+
+FILLER = -1.0e6      # metres; outside every configured point-cloud range
+
+
+class _Frame:
+    __slots__ = ("graph", "points", "valid", "outs")
+
+
+class FrameGraphs:
+    """graphs = FrameGraphs(model); graphs(example) or graphs.forward_deferred(example).result()
+    return what model(example, return_loss=False) returns."""
+
+    def __init__(self, model, bucket=16384, max_graphs=4):
+        if getattr(model, "compute_dtype", None) != torch.bfloat16 or model.training:
+            raise ValueError("FrameGraphs needs a model prepared with to_inference(torch.bfloat16)")
+        self.model, self.bucket, self.max_graphs = model, int(bucket), int(max_graphs)
+        self.frames = OrderedDict()       # (feature count, padded sizes) -> _Frame, least recently used first
+
+    # the frame's launches, no host sync anywhere; None when the ranked head does not apply
+    def _launch(self, points):
+        m = self.model
+        bev, _ = m.extract_feat(dict(points=points, batch_size=len(points)))
+        plan = m.bbox_head.lazy_plan(m.test_cfg)
+        if plan is None:
+            return None
+        return m.bbox_head.predict_lazy(None, bev, m.test_cfg, plan, raw=True)
+
+    def _capture(self, key, pts):
+        F, sizes = key
+        dev = pts[0].device
+        fr = _Frame()
+        fr.points = [torch.full((n, F), FILLER, dtype=torch.float32, device=dev) for n in sizes]
+        fr.valid = [0] * len(sizes)
+        self._fill(fr, pts)
+        # eager once: kernel attributes, folded weights and launch plans are made outside the capture
+        if self._launch(fr.points) is None:
+            return None
+        torch.cuda.synchronize(dev)
+        fr.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(fr.graph):
+            fr.outs = self._launch(fr.points)
+        while len(self.frames) >= self.max_graphs:
+            self.frames.popitem(last=False)
+        self.frames[key] = fr
+        return fr
+
+    @staticmethod
+    def _fill(fr, pts):
+        for b, p in enumerate(pts):
+            n = p.shape[0]
+            fr.points[b][:n].copy_(p)
+            if n < fr.valid[b]:
+                fr.points[b][n:fr.valid[b]].fill_(FILLER)
+            fr.valid[b] = n
+
+    @torch.no_grad()
+    def forward_deferred(self, example):
+        pts = list(example["points"])
+        m = self.model
+        if len(pts) == 0 or pts[0].device.type != "cuda":
+            raise ValueError("FrameGraphs: points must be CUDA tensors, one per sample")
+        key = (pts[0].shape[1], tuple(max(self.bucket, -(-p.shape[0] // self.bucket) * self.bucket) for p in pts))
+        fr = self.frames.get(key)
+        if fr is None:
+            fr = self._capture(key, pts)
+            if fr is None:                # configuration outside the ranked head: plain eager call
+                return ReadyDetections(m(example, return_loss=False))
+        else:
+            self.frames.move_to_end(key)
+            self._fill(fr, pts)
+        fr.graph.replay()
+        outs = tuple(t.clone() for t in fr.outs)     # the next replay overwrites the graph's own buffers
+        return PendingDetections(m.bbox_head, example, outs, lambda: m(example, return_loss=False))
+
+    def __call__(self, example, return_loss=False):
+        assert not return_loss
+        return self.forward_deferred(example).result()
