@@ -22,15 +22,34 @@ class _Frame:
     __slots__ = ("graph", "points", "valid", "outs")
 
 
+class _Lane:
+    """a stream and the graphs captured for it (a graph's buffers belong to one frame in flight)"""
+    __slots__ = ("stream", "frames")
+
+
 class FrameGraphs:
     """graphs = FrameGraphs(model); graphs(example) or graphs.forward_deferred(example).result()
     return what model(example, return_loss=False) returns."""
 
-    def __init__(self, model, bucket=16384, max_graphs=4):
+    def __init__(self, model, bucket=16384, max_graphs=4, lanes=1):
+        """lanes > 1: consecutive frames go round robin to that many streams (default priority), each with its
+        own graphs, so the thin tail of one frame (ranking, NMS: a handful of workgroups) and the latency-bound
+        narrow levels share the chip with another frame's kernels.  Frames still finish in order per lane; a
+        caller that keeps `lanes` frames in flight (forward_deferred) gets the overlap."""
         if getattr(model, "compute_dtype", None) != torch.bfloat16 or model.training:
             raise ValueError("FrameGraphs needs a model prepared with to_inference(torch.bfloat16)")
         self.model, self.bucket, self.max_graphs = model, int(bucket), int(max_graphs)
-        self.frames = OrderedDict()       # (feature count, padded sizes) -> _Frame, least recently used first
+        self.lanes = []
+        for _ in range(int(lanes)):
+            ln = _Lane()
+            ln.stream = torch.cuda.Stream() if lanes > 1 else None      # None: the caller's current stream
+            ln.frames = OrderedDict()     # (feature count, padded sizes) -> _Frame, least recently used first
+            self.lanes.append(ln)
+        self.turn = 0
+
+    @property
+    def frames(self):
+        return self.lanes[0].frames
 
     # the frame's launches, no host sync anywhere; None when the ranked head does not apply
     def _launch(self, points):
@@ -41,7 +60,7 @@ class FrameGraphs:
             return None
         return m.bbox_head.predict_lazy(None, bev, m.test_cfg, plan, raw=True)
 
-    def _capture(self, key, pts):
+    def _capture(self, frames, key, pts):
         F, sizes = key
         dev = pts[0].device
         fr = _Frame()
@@ -55,9 +74,9 @@ class FrameGraphs:
         fr.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(fr.graph):
             fr.outs = self._launch(fr.points)
-        while len(self.frames) >= self.max_graphs:
-            self.frames.popitem(last=False)
-        self.frames[key] = fr
+        while len(frames) >= self.max_graphs:
+            frames.popitem(last=False)
+        frames[key] = fr
         return fr
 
     @staticmethod
@@ -76,13 +95,27 @@ class FrameGraphs:
         if len(pts) == 0 or pts[0].device.type != "cuda":
             raise ValueError("FrameGraphs: points must be CUDA tensors, one per sample")
         key = (pts[0].shape[1], tuple(max(self.bucket, -(-p.shape[0] // self.bucket) * self.bucket) for p in pts))
-        fr = self.frames.get(key)
+        lane = self.lanes[self.turn]
+        self.turn = (self.turn + 1) % len(self.lanes)
+        if lane.stream is None:
+            return self._run(lane, key, pts, example)
+        caller = torch.cuda.current_stream(pts[0].device)
+        lane.stream.wait_stream(caller)               # the points may have been produced on the caller's stream
+        with torch.cuda.stream(lane.stream):
+            pending = self._run(lane, key, pts, example)
+        for t in (pending.boxes, pending.scores, pending.labels) if isinstance(pending, PendingDetections) else ():
+            t.record_stream(caller)                   # results are consumed on the caller's stream
+        return pending
+
+    def _run(self, lane, key, pts, example):
+        m = self.model
+        fr = lane.frames.get(key)
         if fr is None:
-            fr = self._capture(key, pts)
+            fr = self._capture(lane.frames, key, pts)
             if fr is None:                # configuration outside the ranked head: plain eager call
                 return ReadyDetections(m(example, return_loss=False))
         else:
-            self.frames.move_to_end(key)
+            lane.frames.move_to_end(key)
             self._fill(fr, pts)
         fr.graph.replay()
         outs = tuple(t.clone() for t in fr.outs)     # the next replay overwrites the graph's own buffers
