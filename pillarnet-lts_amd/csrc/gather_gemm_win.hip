@@ -590,6 +590,7 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
     return launch_win<128, 64, 4, 1, 4, 64, 288, TOut, true>(a, groups, stream);
   }
   if (f == 'D') return launch_win<128, 256, 2, 2, 4, 64, 192, TOut>(a, groups, stream);
+  if (f == 'E') return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   return launch_win<128, 256, 2, 4, 8, 64, 192, TOut>(a, groups, stream);
 }
 
