@@ -1,6 +1,9 @@
 """CenterHead training losses (det3d/models/losses/centernet_loss.py:9-127, det3d/core/utils/
 center_utils.py:122-226) and `CenterHead.loss` (det3d/models/bbox_heads/center_head.py:133-214).
-Plain torch: these are tiny gathers over <= max_objs targets, not a hot path."""
+Plain torch: these are tiny gathers over <= max_objs targets, not a hot path.  Nothing here reads a value back
+to the host (the reference branches on `mask.sum() == 0`, indexes with boolean masks and moves its log values to
+the CPU per task, ~70 host waits per step): empty tasks fall out of the arithmetic, masked rows are computed on
+stand-in boxes and dropped with `where`, and the log values stay on the device until somebody asks for them."""
 from collections import defaultdict
 
 import torch
@@ -21,16 +24,12 @@ def fast_focal_loss(out, target, ind, mask, cat):
     pos_pred = gather_at(out, ind).gather(2, cat.unsqueeze(2))            # [B,K,1]
     pos = (torch.log(pos_pred) * (1 - pos_pred).pow(2) * mask.unsqueeze(2)).sum()
     num_pos = mask.sum()
-    if num_pos == 0:
-        return -neg
-    return -(pos + neg) / num_pos
+    return -(pos + neg) / num_pos.clamp(min=1.0)      # no positives: pos == 0 and the reference returns -neg
 
 
 def reg_loss(output, mask, ind, target):
     """centernet_loss.py:9-31: masked L1 per box-code element, normalised by the object count."""
-    if mask.sum() == 0:
-        return output.new_zeros((1))
-    pred = gather_at(output, ind)
+    pred = gather_at(output, ind)        # (no objects: every term is 0, as the reference's early return)
     m = mask.float().unsqueeze(2)
     loss = F.l1_loss(pred * m, target * m, reduction="none") / (m.sum() + 1e-4)
     return loss.transpose(2, 0).sum(dim=2).sum(dim=1)
@@ -65,24 +64,33 @@ def axis_aligned_iou3d(pred, gt, kind="IoU"):
     raise NotImplementedError(kind)
 
 
+def _masked_boxes(boxes, m):
+    """rows outside the mask replaced by a unit box at the origin: their IoU is finite, so neither the value nor
+    the gradient of a `where` over the result can pick up a NaN from an all-zero padding row."""
+    unit = boxes.new_zeros(boxes.shape[-1])
+    unit[3:6] = 1.0
+    return torch.where(m.unsqueeze(-1), boxes, unit)
+
+
 def iou_reg_loss(box_pred, mask, ind, box_gt, kind):
     """centernet_loss.py:94-127."""
-    if mask.sum() == 0:
-        return box_pred.new_zeros((1))
     m = mask.bool()
-    pred = gather_at(box_pred, ind)
-    return (1.0 - axis_aligned_iou3d(pred[m], box_gt[m], kind)).sum() / (m.sum() + 1e-4)
+    B, K = m.shape
+    pred, gt = _masked_boxes(gather_at(box_pred, ind), m), _masked_boxes(box_gt, m)
+    iou = axis_aligned_iou3d(pred.reshape(B * K, -1), gt.reshape(B * K, -1), kind)
+    return torch.where(m.reshape(-1), 1.0 - iou, iou.new_zeros(())).sum() / (m.sum() + 1e-4)
 
 
 def iou_loss(iou_pred, mask, ind, box_pred, box_gt):
     """centernet_loss.py:66-91: L1 between the predicted IoU and 2*IoU3D(rotated)-1."""
     from .iou3d_nms import boxes_aligned_iou3d_gpu
-    if mask.sum() == 0:
-        return iou_pred.new_zeros((1))
     m = mask.bool()
-    pred = gather_at(iou_pred, ind)[m]
-    target = 2 * boxes_aligned_iou3d_gpu(gather_at(box_pred, ind)[m], box_gt[m]) - 1
-    return F.l1_loss(pred, target, reduction="sum") / (m.sum() + 1e-4)
+    B, K = m.shape
+    pred = gather_at(iou_pred, ind).reshape(B * K, -1)
+    boxes, gt = _masked_boxes(gather_at(box_pred, ind), m), _masked_boxes(box_gt, m)
+    target = 2 * boxes_aligned_iou3d_gpu(boxes.reshape(B * K, -1).contiguous(), gt.reshape(B * K, -1).contiguous()) - 1
+    err = (pred - target.reshape(pred.shape)).abs()
+    return torch.where(m.reshape(-1, 1), err, err.new_zeros(())).sum() / (m.sum() + 1e-4)
 
 
 def center_head_loss(head, example, preds_dicts, train_cfg):
@@ -102,7 +110,7 @@ def center_head_loss(head, example, preds_dicts, train_cfg):
         box_loss = reg_loss(anno, mask, ind, target_box)
         loc_loss = (box_loss * box_loss.new_tensor(head.code_weights)).sum()
         loss = hm_loss * train_cfg["hm_weight"] + loc_loss * train_cfg["bbox_weight"]
-        ret = {"hm_loss": hm_loss.detach().cpu(), "loc_loss": loc_loss, "loc_loss_elem": box_loss.detach().cpu(),
+        ret = {"hm_loss": hm_loss.detach(), "loc_loss": loc_loss, "loc_loss_elem": box_loss.detach(),
                "num_positive": mask.float().sum()}
         if head.use_iou or head.use_reg_iou:
             B, H, W, _ = pd["dim"].shape
@@ -116,11 +124,11 @@ def center_head_loss(head, example, preds_dicts, train_cfg):
             if head.use_iou:
                 il = iou_loss(pd["iou"], mask, ind, boxes.detach(), example["gt_box"][t])
                 loss = loss + il * train_cfg["iou_weight"]
-                ret["iou_loss"] = il.detach().cpu()
+                ret["iou_loss"] = il.detach()
             if head.use_reg_iou:
                 rl = iou_reg_loss(boxes, mask, ind, example["gt_box"][t], head.reg_iou)
                 loss = loss + rl * train_cfg["reg_iou_weight"]
-                ret["reg_iou_loss"] = rl.detach().cpu()
+                ret["reg_iou_loss"] = rl.detach()
         ret["loss"] = loss
         for k, v in ret.items():
             merged[k].append(v)

@@ -185,6 +185,18 @@ def rulebook_wgrad(feats, nbr, g, n_out):
     return gw
 
 
+_CONST = {}
+
+
+def _const(value, n, dev):
+    """cached fp32 [n] constant (identity scale / zero shift of the un-folded training convs)"""
+    key = (value, n, dev)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), float(value), dtype=torch.float32, device=dev)
+    return t
+
+
 class SparseConvFunction(torch.autograd.Function):
     """Differentiable sparse conv on exact fp32 rows.  Forward and data gradient run the HIP
     implicit GEMM (the gradient is the same gather-GEMM over the INVERSE rulebook with transposed
@@ -195,8 +207,8 @@ class SparseConvFunction(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[3]
         dev = feats.device
         w = weight.detach().permute(1, 2, 0, 3).reshape(9, cout, cin).contiguous().float()
-        ones = torch.ones(cout, device=dev)
-        shift = bias.detach().float().contiguous() if bias is not None else torch.zeros(cout, device=dev)
+        ones = _const(1, cout, dev)
+        shift = bias.detach().float().contiguous() if bias is not None else _const(0, cout, dev)
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
         if n_out > 0:
             rc = _lib.lib().pn_spconv_forward(_lib.PN_DTYPE_F32, _lib.ptr(feats), cin, feats.shape[0], _lib.ptr(nbr),
@@ -220,7 +232,7 @@ class SparseConvFunction(torch.autograd.Function):
             grad_feats = torch.zeros((n_in, cin), dtype=torch.float32, device=dev)
             if n_in > 0 and n_out > 0:
                 wd = weight.detach().permute(1, 2, 3, 0).reshape(9, cin, cout).contiguous().float()   # W_k^T
-                ones, zeros = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+                ones, zeros = _const(1, cin, dev), _const(0, cin, dev)
                 rc = _lib.lib().pn_spconv_forward(_lib.PN_DTYPE_F32, _lib.ptr(g), cout, n_out, _lib.ptr(inv),
                                                   inv.shape[1], _lib.ptr(count_in), n_in, _lib.ptr(wd),
                                                   _lib.ptr(ones), _lib.ptr(zeros), None, 0, _lib.ptr(grad_feats),

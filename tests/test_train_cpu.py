@@ -58,7 +58,11 @@ def test_losses_match_reference():
         il = losses.iou_reg_loss(_t("il.pred"), mask, ind, _t("il.gt"), kind)
         np.testing.assert_allclose(il.numpy(), G[f"il.{kind}"], rtol=1e-5)
     z = torch.zeros_like(mask)
-    assert float(losses.reg_loss(_t("rl.out"), z, ind, _t("rl.target"))) == 0.0
+    assert float(losses.reg_loss(_t("rl.out"), z, ind, _t("rl.target")).abs().sum()) == 0.0
+    assert float(losses.iou_reg_loss(_t("il.pred"), z, ind, _t("il.gt"), "GIoU")) == 0.0
+    fl0 = losses.fast_focal_loss(_t("fl.out"), _t("fl.target"), ind, z, cat)      # no positives: the negative term alone
+    neg = (torch.log(1 - _t("fl.out")) * _t("fl.out").pow(2) * (1 - _t("fl.target")).pow(4)).sum()
+    np.testing.assert_allclose(fl0.numpy(), (-neg).numpy(), rtol=1e-6)
 
 
 def test_center_head_loss_matches_reference():
@@ -184,3 +188,25 @@ def test_point_head_focal_loss_matches_reference():
     loss, tb = ph.get_loss()
     np.testing.assert_allclose(float(loss), float(g["ph.loss"]), rtol=1e-6)
     assert tb["point_pos_num"] == float(g["ph.pos_num"])
+
+
+def test_masked_iou_losses_have_the_compacted_gradient():
+    """the `where`-masked form (no boolean indexing, no host wait) against the reference's compacted form"""
+    torch.manual_seed(3)
+    B, K = 2, 12
+    mask = (torch.rand(B, K) < 0.4).to(torch.uint8)
+    mask[1] = 0                                            # a sample with no objects; padding rows are all-zero boxes
+    ind = torch.randint(0, 64, (B, K))
+    gt = torch.rand(B, K, 7) + 0.5
+    gt = gt * mask.unsqueeze(-1).float()
+    for kind in ("IoU", "GIoU", "DIoU"):
+        a = (torch.rand(B, 8, 8, 7) + 0.5).requires_grad_()
+        got = losses.iou_reg_loss(a, mask, ind, gt, kind)
+        got.backward()
+        b = a.detach().clone().requires_grad_()
+        m = mask.bool()
+        want = (1.0 - losses.axis_aligned_iou3d(losses.gather_at(b, ind)[m], gt[m], kind)).sum() / (m.sum() + 1e-4)
+        want.backward()
+        np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=1e-6)
+        assert torch.isfinite(a.grad).all()
+        np.testing.assert_allclose(a.grad.numpy(), b.grad.numpy(), rtol=1e-5, atol=1e-7)

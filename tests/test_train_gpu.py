@@ -187,7 +187,7 @@ def test_full_size_train_step_batch4(cuda):
     vals = []
     for step in range(3):
         v, losses = trainer.step(ex, step)
-        vals.append(v)
+        vals.append(float(v))
         if step == 0:
             assert len(losses["loss"]) == 6 and all(torch.isfinite(l).all() for l in losses["loss"])
             zero = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
