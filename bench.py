@@ -232,8 +232,16 @@ def run_infer(args):
         runner = model if args.no_graph else FrameGraphs(model, lanes=args.lanes)     # one HIP graph per padded frame shape
         for i in range(args.warmup):
             model(examples[i % len(examples)], return_loss=False)
-            for _ in range(1 if args.no_graph else args.lanes):
-                runner.forward_deferred(examples[i % len(examples)]).result()
+        try:
+            for i in range(max(args.warmup, 1)):
+                for _ in range(1 if args.no_graph else args.lanes):
+                    runner.forward_deferred(examples[i % len(examples)]).result()
+        except RuntimeError as e:      # a runtime that cannot capture: same frames, every kernel queued from Python
+            if args.no_graph:
+                raise
+            print(f"bench.py: frame graph capture failed ({e}); running the eager loop", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            args.no_graph, runner = True, model
         # The timed job: every frame's detections reach the host inside the region.  Frame i+1's kernels are queued
         # before the host waits for frame i's counts, so the GPU works through the host's hand-over.
         barrier()

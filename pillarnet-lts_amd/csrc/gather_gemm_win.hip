@@ -576,13 +576,13 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   if (N <= 32) return unit ? launch_win<256, 32, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                            : launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (N <= 64) {
-    if (unit && work_rows <= 256 * 200) return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
+    if (unit && work_rows <= 256 * 200 && f != 'B') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
     return unit ? launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                 : launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
   if (f == 'T') return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
   if (N <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
-  if (work_rows <= 128 * 160 && N % 128 == 0) {   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
+  if (work_rows <= 128 * 160 && N % 128 == 0 && f != 'B') {   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
     // 128 x 64 tiles (4 compute waves of 32 x 64 + 4 loaders): as many workgroups as 64 x 128 tiles give, but a
     // workgroup streams half the weight bytes for the same MFMAs (the level is bound by DMA issue): +2 % on the
     // frame.  (WMAX 288: a stride-2 run is 2 * 128 + 3 rows.)  'Q' keeps the 64 x 128 shape for comparison.
