@@ -408,6 +408,14 @@ int pn_roi_grid_pool(int dtype, const float* rois, int roi_dim, int batch, int r
                      int grid, const void* map, int map_ld, int H, int W, int C, float x_min,
                      float y_min, float cell_size, float* out, float* points, pnStream stream);
 
+/* Gradient of pn_roi_grid_pool w.r.t. the map (training of the second stage): grad_out [batch, rois_per_sample,
+ * grid*grid, C] fp32 -> grad_map [batch, H*W, C] fp32, which must be ZERO on entry (fp32 atomic adds into the
+ * four bilinear corners of every grid point).  The reference has no kernel here: autograd differentiates the
+ * gathers of bilinear_interpolate_torch (det3d/core/utils/center_utils.py:91-120). */
+int pn_roi_grid_pool_grad(const float* rois, int roi_dim, int batch, int rois_per_sample, int grid,
+                          const float* grad_out, int H, int W, int C, float x_min, float y_min,
+                          float cell_size, float* grad_map, pnStream stream);
+
 /* ------------------------------------------------------------------------
  * points_in_boxes_2d_gpu of the reference's roiaware_pool3d extension (the PointHead target assigner of
  * Pillar R-CNN): det3d/ops/roiaware_pool3d/src/roiaware_pool3d.cpp (points_in_boxes_2d_gpu),

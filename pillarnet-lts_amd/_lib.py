@@ -117,6 +117,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_roi_grid_pool": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "pn_roi_grid_pool_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
+                                      c_float, c_float, c_void_p, c_void_p]),
     "pn_points_in_boxes_2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_points_to_voxel": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),

@@ -77,6 +77,64 @@ extern "C" int pn_roi_grid_pool(int dtype, const float* rois, int roi_dim, int b
   return PN_OK;
 }
 
+// Gradient of the pooling w.r.t. the map: every grid point adds grad_out * (its four bilinear weights) to its four
+// corner rows of grad_map (fp32 atomics; the reference's autograd does the same through index_put/gather
+// backward of bilinear_interpolate_torch, center_utils.py:91-120).  grad_map must be zero on entry.
+__global__ __launch_bounds__(256) void roi_grid_pool_grad_kernel(
+    const float* __restrict__ rois, int roi_dim, int B, int R, int G, const float* __restrict__ grad_out, int H,
+    int W, int C, float x_min, float y_min, float inv_cell, float* __restrict__ grad_map) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long long total = (long long)B * R * G * G;
+  if (wave >= total) return;
+  const int gp = (int)(wave % (G * G));
+  const long long r = wave / (G * G);
+  const int b = (int)(r / R);
+  const float* roi = rois + r * roi_dim;
+  const float cx = roi[0], cy = roi[1], dx = roi[3], dy = roi[4], ang = roi[roi_dim - 1];
+  const int i = gp / G, j = gp % G;
+  const float lx = ((float)i + 0.5f) / (float)G * dx - dx / 2;
+  const float ly = ((float)j + 0.5f) / (float)G * dy - dy / 2;
+  const float s = sinf(ang), c = cosf(ang);
+  const float px = lx * c + ly * s + cx;
+  const float py = -lx * s + ly * c + cy;
+  const float x = (px - x_min) * inv_cell, y = (py - y_min) * inv_cell;
+  int x0 = (int)floorf(x), y0 = (int)floorf(y);
+  int x1 = x0 + 1, y1 = y0 + 1;
+  x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+  y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+  const float wa = ((float)x1 - x) * ((float)y1 - y), wb = ((float)x1 - x) * (y - (float)y0);
+  const float wc = (x - (float)x0) * ((float)y1 - y), wd = (x - (float)x0) * (y - (float)y0);
+  float* base = grad_map + (size_t)b * H * W * C;
+  float* Ga = base + ((size_t)y0 * W + x0) * C;
+  float* Gb = base + ((size_t)y1 * W + x0) * C;
+  float* Gc = base + ((size_t)y0 * W + x1) * C;
+  float* Gd = base + ((size_t)y1 * W + x1) * C;
+  const float* g = grad_out + wave * C;
+  for (int ch = lane; ch < C; ch += 64) {
+    const float v = g[ch];
+    atomicAdd(Ga + ch, v * wa);
+    atomicAdd(Gb + ch, v * wb);
+    atomicAdd(Gc + ch, v * wc);
+    atomicAdd(Gd + ch, v * wd);
+  }
+}
+
+extern "C" int pn_roi_grid_pool_grad(const float* rois, int roi_dim, int batch, int rois_per_sample, int grid,
+                                     const float* grad_out, int H, int W, int C, float x_min, float y_min,
+                                     float cell_size, float* grad_map, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(rois && grad_out && grad_map && roi_dim >= 7 && batch >= 1 && rois_per_sample >= 0 && grid >= 1 &&
+                   C >= 1 && H >= 1 && W >= 1 && cell_size > 0.f,
+               "pn_roi_grid_pool_grad: bad argument");
+  const long long waves = (long long)batch * rois_per_sample * grid * grid;
+  if (waves == 0) return PN_OK;
+  hipLaunchKernelGGL(roi_grid_pool_grad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, rois, roi_dim,
+                     batch, rois_per_sample, grid, grad_out, H, W, C, x_min, y_min, 1.0f / cell_size, grad_map);
+  PN_CHECK_LAUNCH("roi_grid_pool_grad_kernel");
+  return PN_OK;
+}
+
 // ---- points_in_boxes_2d (det3d/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:16-21,39-50,354-377) ----
 // boxes [B, T, 7] in pcdet convention (x, y, z, dx, dy, dz, heading), pts [B, M, 2]; out [B, M] = index of the
 // FIRST box whose BEV rectangle (+1e-5 margin) holds the point, else -1.

@@ -77,6 +77,29 @@ def boxes_iou_bev(boxes_a, boxes_b):
     return _pairwise(boxes_a, boxes_b, False, True)
 
 
+def _staged_iou(boxes_a, boxes_b, ans_iou, aligned):
+    if not torch.cuda.is_available():
+        raise _lib.PillarnetHipError("boxes_*_iou_bev_cpu: the rotated IoU runs on the GPU (no CPU fallback)")
+    assert boxes_a.is_contiguous() and boxes_b.is_contiguous()          # CHECK_CONTIGUOUS, iou3d_cpu.cpp:237-238
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = _pairwise(boxes_a.to(dev), boxes_b.to(dev), aligned, True)
+    ans_iou.copy_(out.view(ans_iou.shape))
+    return 1
+
+
+def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
+    """`iou3d_nms_cuda.boxes_iou_bev_cpu(a [N,7], b [M,7], ans [N,M]) -> 1` (iou3d_cpu.cpp:232-252): host tensors
+    in and out.  The reference loops `iou_bev` over the pairs on the CPU; here the pairs go through the same HIP
+    kernel as boxes_iou_bev_gpu on a staged copy (this package computes nothing on the CPU)."""
+    return _staged_iou(boxes_a, boxes_b, ans_iou, False)
+
+
+def boxes_aligned_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
+    """`iou3d_nms_cuda.boxes_aligned_iou_bev_cpu(a [N,7], b [N,7], ans [N,1]) -> 1` (iou3d_cpu.cpp:254-273)."""
+    assert boxes_a.shape[0] == boxes_b.shape[0]
+    return _staged_iou(boxes_a, boxes_b, ans_iou, True)
+
+
 def boxes_overlap_bev(boxes_a, boxes_b):
     return _pairwise(boxes_a, boxes_b, False, False)
 

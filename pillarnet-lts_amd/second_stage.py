@@ -54,6 +54,41 @@ def roi_grid_pool(rois, feature_map, grid, cell_size, x_min, y_min, want_points=
     return roi_grid_pool_rows(rois, r.t, r.B, r.H, r.W, grid, cell_size, x_min, y_min, want_points)
 
 
+class RoIGridPoolFunction(torch.autograd.Function):
+    """Differentiable RoI pillar pooling on the HIP kernels: forward = pn_roi_grid_pool on the fp32 pixel rows,
+    backward = pn_roi_grid_pool_grad (the map's gradient; RoIs are first-stage boxes and carry none)."""
+
+    @staticmethod
+    def forward(ctx, rois, feature_map, grid, cell_size, x_min, y_min):
+        B, C, H, W = feature_map.shape
+        rows = feature_map.detach().permute(0, 2, 3, 1).reshape(B * H * W, C).float().contiguous()
+        rois = rois.detach().contiguous().float()
+        out, pts = roi_grid_pool_rows(rois, rows, B, H, W, grid, cell_size, x_min, y_min, True)
+        ctx.save_for_backward(rois)
+        ctx.geom = (B, C, H, W, grid, cell_size, x_min, y_min, feature_map.dtype)
+        ctx.mark_non_differentiable(pts)
+        return out, pts
+
+    @staticmethod
+    def backward(ctx, g, _g_pts):
+        (rois,) = ctx.saved_tensors
+        B, C, H, W, grid, cell_size, x_min, y_min, dtype = ctx.geom
+        gm = torch.zeros((B, H * W, C), dtype=torch.float32, device=g.device)
+        g = g.contiguous().float()
+        rc = _lib.lib().pn_roi_grid_pool_grad(_lib.ptr(rois), rois.shape[2], B, rois.shape[1], grid, _lib.ptr(g), H, W, C,
+                                              float(np.float32(x_min)), float(np.float32(y_min)),
+                                              float(np.float32(cell_size)), _lib.ptr(gm), _lib.current_stream(g.device))
+        _lib.check(rc, "pn_roi_grid_pool_grad")
+        return None, gm.view(B, H, W, C).permute(0, 3, 1, 2).to(dtype), None, None, None, None
+
+
+def roi_grid_pool_train(rois, feature_map, grid, cell_size, x_min, y_min):
+    """training-mode pooling: ([B,R,G*G,C] fp32 with a gradient path to `feature_map`, grid points)."""
+    if rois.requires_grad:
+        raise _lib.PillarnetHipError("roi_grid_pool_train: RoIs are constants of the second stage (detach them)")
+    return RoIGridPoolFunction.apply(rois, feature_map, grid, cell_size, x_min, y_min)
+
+
 def roi_grid_pool_torch(rois, feature_map, grid, cell_size, x_min, y_min):
     """The same pooling as a differentiable torch expression (training: gradients reach the fused map through
     the gathers): center_to_grid_box2d + rotation_2d (box_torch_ops.py:220-251) and bilinear_interpolate_torch
@@ -196,8 +231,9 @@ class BEVStrideFeature(nn.Module):
     def forward(self, example):
         B, R = example["rois"].shape[:2]
         fmap = self.fused_map(example)
-        if fmap.requires_grad:      # training: differentiable torch expression of the same pooling
-            pooled, pts = roi_grid_pool_torch(example["rois"], fmap, self.grid_size, self.out_stride * self.pillar_size,
+        if fmap.requires_grad:      # training: the same kernel forward, the map's gradient through its HIP backward
+            pooled, pts = roi_grid_pool_train(example["rois"].detach(), fmap, self.grid_size,
+                                              self.out_stride * self.pillar_size,
                                               self.point_cloud_range[0], self.point_cloud_range[1])
         else:
             r = dense_hip.Rows.from_nchw(fmap)

@@ -81,6 +81,21 @@ def test_iou_matrix(cuda):
     np.testing.assert_allclose(got_ov, want_ov, rtol=1e-5, atol=1e-4)
 
 
+def test_cpu_named_iou_entries(cuda):
+    """boxes_iou_bev_cpu / boxes_aligned_iou_bev_cpu: host tensors in and out, values of the reference's iou_bev"""
+    a = synth.nms_boxes(150, seed=5, cluster=2.0)
+    b = synth.nms_boxes(150, seed=6, cluster=2.0)
+    b[:80, :2] = a[:80, :2] + 0.25
+    want = iou3d.iou_matrix(a, b)
+    ans = torch.zeros(150, 150)
+    assert iou3d_nms.boxes_iou_bev_cpu(torch.from_numpy(a), torch.from_numpy(b), ans) == 1
+    np.testing.assert_allclose(ans.numpy(), want, rtol=0, atol=IOU_TOL)
+    ans1 = torch.zeros(150, 1)
+    assert iou3d_nms.boxes_aligned_iou_bev_cpu(torch.from_numpy(a), torch.from_numpy(b), ans1) == 1
+    np.testing.assert_allclose(ans1.numpy()[:, 0], np.diag(want), rtol=0, atol=IOU_TOL)
+    assert (np.diag(want) > 0).sum() > 40
+
+
 def test_batched_sets_with_device_counts(cuda):
     S, cap = 6, 1000
     sets = [synth.nms_boxes(cap, seed=50 + s, cluster=1.5) for s in range(S)]

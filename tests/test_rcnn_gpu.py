@@ -249,6 +249,26 @@ def test_roi_grid_pool_torch_equals_kernel_and_carries_gradients(cuda):
     assert fmap.grad is not None and float(fmap.grad.abs().sum()) > 0
 
 
+def test_roi_grid_pool_hip_backward_equals_autograd(cuda):
+    """pn_roi_grid_pool_grad against autograd through the torch expression of the same pooling"""
+    rs = np.random.RandomState(4)
+    rois = torch.from_numpy(_rois(rs, 2, 11, 8.0)).to(cuda)
+    base = torch.randn(2, 24, 40, 56, device=cuda)
+    w = torch.randn(2, 11, 49, 24, device=cuda)
+    a = base.clone().requires_grad_()
+    got, pts = second_stage.roi_grid_pool_train(rois, a, 7, 0.4, -11.2, -8.0)
+    (got * w).sum().backward()
+    b = base.clone().requires_grad_()
+    want, wpts = second_stage.roi_grid_pool_torch(rois, b, 7, 0.4, -11.2, -8.0)
+    (want * w).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(pts.cpu().numpy(), wpts.detach().cpu().numpy(), atol=4e-6)
+    assert float(b.grad.abs().sum()) > 0
+    np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), atol=2e-3, rtol=1e-3)
+    with pytest.raises(Exception):
+        second_stage.roi_grid_pool_train(rois.clone().requires_grad_(), a, 7, 0.4, -11.2, -8.0)
+
+
 def test_pillarrcnn_train_step(cuda):
     """Whole two-stage training forward/backward on a small frame: every loss finite, first- and second-stage
     parameters receive gradients, the loss falls on a repeated batch."""
