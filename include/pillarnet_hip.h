@@ -361,6 +361,12 @@ int pn_create_pillar_indices(const int32_t* pillars_position, int B, int H, int 
 int pn_gather_indice(const int32_t* index, int L, const int32_t* indices, int32_t* outs, pnStream stream);
 int pn_gather_feature(const int32_t* index, int L, const float* features, int C, float* outs,
                       pnStream stream);
+/* pillar_cuda.gather_feature_grad_wrapper (group_ops.cpp:41-57; kernel group_ops_gpu.cu:35-48):
+ * grad_features[index[l], :] += grad_outs[l, :] (fp32 atomics; grad_features is accumulated into, the caller
+ * zeroes it).  Argument order of the C++ binding; the reference's Python caller (group_utils.py:28-35) passes
+ * (index, grad_outs, grad_features) and is never reached, because its one input is detached. */
+int pn_gather_feature_grad(const float* grad_outs, const int32_t* index, int L, int C, float* grad_features,
+                           pnStream stream);
 /* pillar_cuda.scatter_max_wrapper (scatter_ops.cpp:7-24): out[m,c] = max(0, max_{p: index[p]=m}
  * src[p,c]); arg may be NULL.  One pass, deterministic.  workspace: pn_scatter_max_workspace_bytes(M, C).
  * `arg` is NOT the reference's encoding: the reference's second pass (scatter_ops_gpu.cu:24-36) stores the

@@ -107,6 +107,7 @@ SIGNATURES = {
     "pn_create_pillar_indices": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_gather_indice": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "pn_gather_feature": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "pn_gather_feature_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pn_scatter_max_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pn_scatter_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),

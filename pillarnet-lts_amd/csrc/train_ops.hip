@@ -70,6 +70,19 @@ __global__ __launch_bounds__(T) void gather_feature_kernel(long long total, int 
   }
 }
 
+// gather_feature backward (group_ops_gpu.cu:35-48): grad_features[index[l]] += grad_outs[l]; one lane per
+// (l, c) so the adds of a row are coalesced (the reference walks a row's channels in one thread)
+__global__ __launch_bounds__(T) void gather_feature_grad_kernel(long long total, int C,
+                                                                const int32_t* __restrict__ index,
+                                                                const float* __restrict__ grad_outs,
+                                                                float* __restrict__ grad_feats) {
+  for (long long t = (long long)blockIdx.x * T + threadIdx.x; t < total; t += (long long)gridDim.x * T) {
+    const long long i = t / C;
+    const int c = (int)(t - i * C);
+    atomicAdd(grad_feats + (size_t)index[i] * C + c, grad_outs[t]);
+  }
+}
+
 // ---- scatter max -------------------------------------------------------------------------------
 __global__ __launch_bounds__(T) void scatter_max_pack_kernel(long long total, int C,
                                                              const int32_t* __restrict__ index,
@@ -162,6 +175,15 @@ extern "C" int pn_gather_feature(const int32_t* index, int L, const float* featu
   if (L == 0) return PN_OK;
   PN_CHECK_ARG(index && features && outs && C >= 1, "pn_gather_feature: null argument");
   LAUNCH(gather_feature_kernel, (long long)L * C, (long long)L * C, C, index, features, outs);
+  return PN_OK;
+}
+
+extern "C" int pn_gather_feature_grad(const float* grad_outs, const int32_t* index, int L, int C,
+                                      float* grad_features, pnStream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (L == 0) return PN_OK;
+  PN_CHECK_ARG(index && grad_outs && grad_features && C >= 1, "pn_gather_feature_grad: null argument");
+  LAUNCH(gather_feature_grad_kernel, (long long)L * C, (long long)L * C, C, index, grad_outs, grad_features);
   return PN_OK;
 }
 

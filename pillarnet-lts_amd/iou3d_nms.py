@@ -175,3 +175,29 @@ def nms_normal_gpu(boxes, scores, thresh, **kwargs):
     keep = torch.LongTensor(boxes.size(0))
     num_out = nms_normal_gpu_raw(boxes, keep, thresh)
     return order[keep[:num_out].to(boxes.device)].contiguous(), None
+
+
+class iou3d_nms_cuda:
+    """Drop-in for the reference's `iou3d_nms_cuda` pybind module (iou3d_nms_api.cpp:11-19): same names, argument
+    order and out-parameter style; boxes [n, 7] fp32 in the pcdet frame, results written into the caller's tensor."""
+
+    @staticmethod
+    def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
+        ans_overlap.copy_(_pairwise(boxes_a, boxes_b, False, False))
+        return 1
+
+    @staticmethod
+    def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
+        ans_iou.copy_(_pairwise(boxes_a, boxes_b, False, True))
+        return 1
+
+    @staticmethod
+    def boxes_aligned_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
+        assert boxes_a.shape[0] == boxes_b.shape[0]
+        ans_overlap.copy_(_pairwise(boxes_a, boxes_b, True, False).view(ans_overlap.shape))
+        return 1
+
+    nms_gpu = staticmethod(nms_gpu_raw)
+    nms_normal_gpu = staticmethod(nms_normal_gpu_raw)
+    boxes_iou_bev_cpu = staticmethod(boxes_iou_bev_cpu)
+    boxes_aligned_iou_bev_cpu = staticmethod(boxes_aligned_iou_bev_cpu)

@@ -211,6 +211,13 @@ class pillar_cuda:
         return 1
 
     @staticmethod
+    def gather_feature_grad_wrapper(grad_outs, index, grad_features):
+        rc = _lib.lib().pn_gather_feature_grad(_lib.ptr(grad_outs), _lib.ptr(index), index.shape[0], grad_outs.shape[1],
+                                               _lib.ptr(grad_features), _lib.current_stream(grad_outs.device))
+        _lib.check(rc, "pn_gather_feature_grad")
+        return 1
+
+    @staticmethod
     def scatter_max_wrapper(index, src, arg, out):
         L, C = src.shape
         M = out.shape[0]
@@ -268,11 +275,30 @@ def gather_indice(indices, index):
     return outs
 
 
+class GatherFeature(torch.autograd.Function):
+    """group_utils.py:16-36: outs[l] = features[index[l]]; the backward adds grad_outs[l] into row index[l]
+    (the reference's own backward passes its arguments in the wrong order and is unreachable: its one caller
+    detaches the input, pillar_modules.py:71)."""
+
+    @staticmethod
+    def forward(ctx, features, index):
+        index = _cuda_i32(index, "gather_feature")
+        feats = _cuda_i32(features.detach(), "gather_feature")
+        outs = feats.new_zeros((index.shape[0], feats.shape[1]))
+        pillar_cuda.gather_feature_wrapper(index, feats, outs)
+        ctx.for_backwards = (feats.shape[0], feats.shape[1], index)
+        return outs
+
+    @staticmethod
+    def backward(ctx, grad_outs):
+        N, C, index = ctx.for_backwards
+        grad_features = grad_outs.new_zeros(N, C)
+        pillar_cuda.gather_feature_grad_wrapper(grad_outs.contiguous().float(), index, grad_features)
+        return grad_features, None
+
+
 def gather_feature(features, index):
-    """group_utils.py:16-38 forward (the reference detaches its only input, pillar_modules.py:71)."""
-    outs = features.new_zeros((index.shape[0], features.shape[1]))
-    pillar_cuda.gather_feature_wrapper(_cuda_i32(index, "gather_feature"), _cuda_i32(features, "gather_feature"), outs)
-    return outs
+    return GatherFeature.apply(features, index)
 
 
 def query_and_group(groups: PillarQueryAndGroup, pts_xy, pts_batch_cnt, pts_features):

@@ -96,6 +96,28 @@ def test_cpu_named_iou_entries(cuda):
     assert (np.diag(want) > 0).sum() > 40
 
 
+def test_pybind_shaped_module(cuda):
+    """iou3d_nms_cuda.*: out-parameter style of iou3d_nms_api.cpp:11-19"""
+    m = iou3d_nms.iou3d_nms_cuda
+    a = synth.nms_boxes(90, seed=8, cluster=2.0)
+    b = synth.nms_boxes(70, seed=9, cluster=2.0)
+    b[:50, :2] = a[:50, :2] + 0.2
+    ta, tb = torch.from_numpy(a).to(cuda), torch.from_numpy(b).to(cuda)
+    ans = torch.zeros(90, 70, device=cuda)
+    assert m.boxes_iou_bev_gpu(ta, tb, ans) == 1
+    np.testing.assert_allclose(ans.cpu().numpy(), iou3d.iou_matrix(a, b), rtol=0, atol=IOU_TOL)
+    assert m.boxes_overlap_bev_gpu(ta, tb, ans) == 1
+    want_ov = iou3d.iou_matrix(a, b, overlap_only=True)
+    np.testing.assert_allclose(ans.cpu().numpy(), want_ov, rtol=1e-5, atol=1e-4)
+    al = torch.zeros(70, 1, device=cuda)
+    assert m.boxes_aligned_overlap_bev_gpu(ta[:70], tb, al) == 1
+    np.testing.assert_allclose(al.cpu().numpy()[:, 0], np.diag(want_ov[:70]), rtol=1e-5, atol=1e-4)
+    keep = torch.LongTensor(90)
+    n = m.nms_gpu(ta, keep, 0.2)
+    assert_keep_lists_match(keep[:n].numpy(), iou3d.nms(a, 0.2)[0], a, 0.2)
+    assert m.nms_normal_gpu(ta, keep, 0.3) > 0
+
+
 def test_batched_sets_with_device_counts(cuda):
     S, cap = 6, 1000
     sets = [synth.nms_boxes(cap, seed=50 + s, cluster=1.5) for s in range(S)]

@@ -28,6 +28,24 @@ def test_pillar_cuda_surface_matches_oracle(cuda):
     np.testing.assert_allclose(f.cpu().numpy(), want_f, rtol=0, atol=1e-6)
 
 
+def test_gather_feature_backward(cuda):
+    """GatherFeature (group_utils.py:16-36) and pillar_cuda.gather_feature_grad_wrapper: rows gathered with
+    repeats, gradient = scatter-add of the incoming rows"""
+    from pillarnet_lts_amd import pillar_ops
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(37, 6, generator=g).to(cuda).requires_grad_()
+    index = torch.randint(0, 37, (500,), generator=g).int().to(cuda)
+    w = torch.randn(500, 6, generator=g).to(cuda)
+    out = pillar_ops.gather_feature(feats, index)
+    assert torch.equal(out, feats.detach()[index.long()])
+    (out * w).sum().backward()
+    want = torch.zeros(37, 6, device=cuda).index_add_(0, index.long(), w)
+    np.testing.assert_allclose(feats.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    acc = torch.ones(37, 6, device=cuda)               # the raw wrapper accumulates into what it is given
+    assert pillar_ops.pillar_cuda.gather_feature_grad_wrapper(w, index, acc) == 1
+    np.testing.assert_allclose(acc.cpu().numpy(), (want + 1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def test_scatter_max_forward_backward(cuda):
     rng = np.random.default_rng(1)
     L, C, M = 5000, 32, 700
