@@ -43,6 +43,7 @@ def parse(argv=None):
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="frames in flight per GPU, one stream each")
+    ap.add_argument("--no-shared-cu-tiles", action="store_true", help="record the graphs with the one-launch-owns-the-chip tiles")
     ap.add_argument("--no-graph", action="store_true", help="queue every kernel from Python instead of replaying the frame's HIP graph")
     ap.add_argument("--cpu-baseline-1t", action="store_true",
                     help="also time the whole oracle frame on ONE thread (minutes)")
@@ -229,7 +230,7 @@ def run_infer(args):
     with torch.no_grad():
         from pillarnet_lts_amd import FrameGraphs
         args.no_graph = args.no_graph or dtype != torch.bfloat16
-        runner = model if args.no_graph else FrameGraphs(model, lanes=args.lanes)     # one HIP graph per padded frame shape
+        runner = model if args.no_graph else FrameGraphs(model, lanes=args.lanes, shared_cu_tiles=False if args.no_shared_cu_tiles else None)     # one HIP graph per padded frame shape
         for i in range(args.warmup):
             model(examples[i % len(examples)], return_loss=False)
         try:

@@ -305,6 +305,12 @@ int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_rows, const 
                    int res_ld, int relu, void* out, int out_ld, int out_fp32,
                    const int32_t* out_rows, pnStream stream);
 
+/* Tile policy of the gather-GEMM launches (process-wide; returns the previous value; no counterpart in the
+ * reference).  0 = a launch has the chip to itself (default).  1 = the caller keeps several frames in flight on
+ * different streams: tiles are chosen so that two workgroups fit one CU and the frames' kernels share the chip.
+ * Results are bit-identical under both.  A HIP graph keeps the tiles it was captured with. */
+int pn_gg_set_tile_policy(int policy);
+
 /* Grouped form of pn_gather_gemm: `groups` problems over the same rows / rulebook; group g reads the
  * channel slice starting at in + g*in_group_cols, uses weight + g*ntaps*cout*cin and
  * scale/shift + g*cout, and writes out + g*out_group_cols.  (CenterHead's per-task output convs,

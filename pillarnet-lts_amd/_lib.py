@@ -95,6 +95,7 @@ SIGNATURES = {
     "pn_gather_gemm": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                c_void_p, c_void_p]),
+    "pn_gg_set_tile_policy": (c_int, [c_int]),
     "pn_gather_gemm_grouped": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p, ctypes.c_longlong, c_void_p]),

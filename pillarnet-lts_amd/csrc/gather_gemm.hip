@@ -407,6 +407,8 @@ static unsigned gg_in_bytes(long long in_rows, int in_ld) {
   return (in_rows > 0 && b < (long long)GG_OOB) ? (unsigned)b : 0u;   // 0 -> register staging
 }
 
+thread_local int pn_gg_free_order = 0;
+
 extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_rows, const int32_t* nbr, int nbr_stride, int ntaps,
                               const int32_t* count_dev, int rows, const void* weight, int cout,
                               const float* scale, const float* shift, const void* residual,
@@ -432,6 +434,7 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.out = out; a.out_ld = out_ld; a.out_rows = out_rows;
   a.g_in = a.g_wt = a.g_ss = a.g_out = a.g_rows = a.g_nbr = a.g_count = 0;
   { const char* d = getenv("PN_GG_DIAG"); a.diag = d ? atoi(d) : 0; }
+  a.free_order = pn_gg_free_order;
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   {
     const int rc = pn_gg_try_window(a, 1, out_fp32 != 0, stream);   // 3x3 rulebooks: window-staged kernel
@@ -499,6 +502,7 @@ static int gather_gemm_grouped_impl(const void* in, int cin, int in_ld, long lon
   a.g_nbr = nbr_group_stride;
   a.g_count = count_dev ? 1 : 0;
   a.diag = 0;
+  a.free_order = 0;
   {
     const int rc = pn_gg_try_window(a, groups, out_fp32 != 0, stream);
     if (rc != -1) return rc;

@@ -559,10 +559,24 @@ static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
 //                256-wide shape); 128 x 64 unit-stage tiles when the level is small (a 90 x 90 map is 64 tiles of
 //                128 x 256 on 256 CUs: filling the chip wins 2x although every tile then streams its weights itself)
 // PN_GG_WIN_CFG (tuning / tests): P = per-tap stages everywhere, D = 128 x 256 on 4 + 4 waves, T = 128 x 128 tiles
-// with a 2-deep weight ring (two workgroups per CU; within 3 % of the default on every shape measured).
+// with a 2-deep weight ring on the 256-wide shapes too (two workgroups per CU; within 3 % of the default there),
+// E = 256 x 128 tiles on 256-wide shapes, B = big tiles on small levels, h / t = the two-workgroup narrow configs off.
+// Tile policy.  0 (default): a launch is alone on the chip, so small levels get small tiles that fill it.
+// 1: the caller keeps several frames in flight on different streams; what counts is CU-time, and a workgroup
+// whose LDS pool stays under 80 KB can share a CU with a workgroup of the other frame's kernel -- 128 x 128 tiles
+// with the 2-deep ring everywhere above 64 outputs.  Same stage order and k-chunking as the default tiles, so
+// the results are bit-identical under either policy.
+static int g_tile_policy = 0;
+extern "C" int pn_gg_set_tile_policy(int policy) {
+  const int old = g_tile_policy;
+  if (policy == 0 || policy == 1) g_tile_policy = policy;
+  return old;
+}
+
 template <typename TOut>
 static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   const int N = a.cout_total;
+  const bool shared_cu = g_tile_policy == 1;
   static const char* force = getenv("PN_GG_WIN_CFG");
   const char f = force ? force[0] : 0;
   const bool unit = f != 'P';
@@ -576,11 +590,19 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   if (N <= 32) return unit ? launch_win<256, 32, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                            : launch_win<256, 32, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (N <= 64) {
+    // 64 -> 64 on a large level: 32-channel units keep the pool at 79 KB, so two workgroups share a CU and one's
+    // prologue / epilogue (half of a tile's time on this level) runs under the other's units: 42.0 -> 34.8 us on
+    // the 245 k-row level.  Wider inputs (256 -> 64) lose more to the doubled unit count than they gain.  'h' = off.
+    // 32-channel chunks change the summation order, so only launches that declare `free_order` (the sparse
+    // backbone) take it: the ranked head must reproduce the dense head's bits from another launch shape.
+    if (unit && a.cin == 64 && a.free_order && f != 'h') return launch_win<256, 64, 4, 1, 4, 32, 320, TOut, true>(a, groups, stream);
     if (unit && work_rows <= 256 * 200 && f != 'B') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
     return unit ? launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                 : launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
-  if (f == 'T') return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
+  // <= 128 outputs: 128 x 128 tiles with a 2-deep weight ring (77 KB, two workgroups per CU): 53.0 -> 50.6 us on the
+  // 111 k-row 128 -> 128 level against 256 x 128 tiles that own a CU.  't' = off.
+  if (f == 'T' || ((N <= 128 || shared_cu) && f != 't')) return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
   if (N <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (work_rows <= 128 * 160 && N % 128 == 0 && f != 'B') {   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
     // 128 x 64 tiles (4 compute waves of 32 x 64 + 4 loaders): as many workgroups as 64 x 128 tiles give, but a

@@ -46,7 +46,13 @@ struct GGArgs {
   // grouped launch (blockIdx.z = group g): element offsets added per group
   long long g_in, g_wt, g_ss, g_out, g_rows, g_nbr, g_count;
   int diag;                // 1: skip LDS reads + MFMAs (staging-rate probe), 2: skip staging (math-rate probe)
+  int free_order;          // 1: the caller compares this conv with no other launch shape of the same weights (a sparse
+                           // backbone level), so the tile may pick its own channel chunking; 0: the summation order is
+                           // a function of (cin, taps) alone
 };
+
+// set by pn_spconv_forward around its pn_gather_gemm call (host threads launch independently)
+extern thread_local int pn_gg_free_order;
 
 // out-of-range offset: a buffer load through a descriptor drops it and delivers zeros -- how a
 // missing neighbour (or a weight row past cout) becomes a zero LDS row on the LDS-DMA path

@@ -20,6 +20,7 @@
 // scale/shift (+ residual, ReLU) and stores 8 B (bf16) / 16 B (fp32) per lane straight into the
 // row-major [M, C] output.  The fp32 build uses v_mfma_f32_16x16x4_f32 with the same 16-B loads.
 #include "common.h"
+#include "gg_common.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -277,8 +278,13 @@ extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, long long i
                  (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
                "pn_spconv_forward: pointers must be 16-B aligned");
   if (dtype == PN_DTYPE_BF16 && !getenv("PN_SPCONV_V1"))  // LDS-tiled kernel (gather_gemm.hip)
-    return pn_gather_gemm(in, cin, cin, in_rows, nbr, nbr_stride, 9, count_dev, cap, weight, cout, scale, shift, residual,
-                          cout, relu, out, cout, 0, nullptr, stream_);
+  {
+    pn_gg_free_order = 1;   // a backbone level: nothing else evaluates these weights at another launch shape
+    const int rc = pn_gather_gemm(in, cin, cin, in_rows, nbr, nbr_stride, 9, count_dev, cap, weight, cout, scale, shift,
+                                  residual, cout, relu, out, cout, 0, nullptr, stream_);
+    pn_gg_free_order = 0;
+    return rc;
+  }
   PN_CONV_CASE(32, 32, 4)
   PN_CONV_CASE(32, 64, 4)
   PN_CONV_CASE(64, 64, 4)

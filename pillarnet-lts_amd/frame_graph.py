@@ -13,6 +13,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import _lib
 from .bbox_heads import PendingDetections, ReadyDetections
 
 FILLER = -1.0e6      # metres; outside every configured point-cloud range
@@ -31,7 +32,7 @@ class FrameGraphs:
     """graphs = FrameGraphs(model); graphs(example) or graphs.forward_deferred(example).result()
     return what model(example, return_loss=False) returns."""
 
-    def __init__(self, model, bucket=16384, max_graphs=4, lanes=1):
+    def __init__(self, model, bucket=16384, max_graphs=4, lanes=1, shared_cu_tiles=None):
         """lanes > 1: consecutive frames go round robin to that many streams (default priority), each with its
         own graphs, so the thin tail of one frame (ranking, NMS: a handful of workgroups) and the latency-bound
         narrow levels share the chip with another frame's kernels.  Frames still finish in order per lane; a
@@ -46,6 +47,7 @@ class FrameGraphs:
             ln.frames = OrderedDict()     # (feature count, padded sizes) -> _Frame, least recently used first
             self.lanes.append(ln)
         self.turn = 0
+        self.shared_cu_tiles = lanes > 1 if shared_cu_tiles is None else bool(shared_cu_tiles)
 
     @property
     def frames(self):
@@ -53,6 +55,14 @@ class FrameGraphs:
 
     # the frame's launches, no host sync anywhere; None when the ranked head does not apply
     def _launch(self, points):
+        # with several lanes the graphs are recorded with tiles that let two frames' workgroups share a CU
+        old = _lib.lib().pn_gg_set_tile_policy(1 if self.shared_cu_tiles else 0)
+        try:
+            return self._launch_frame(points)
+        finally:
+            _lib.lib().pn_gg_set_tile_policy(old)
+
+    def _launch_frame(self, points):
         m = self.model
         bev, _ = m.extract_feat(dict(points=points, batch_size=len(points)))
         plan = m.bbox_head.lazy_plan(m.test_cfg)
