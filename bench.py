@@ -51,9 +51,9 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="gloo + CPU no-op step (launcher test)")
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = 30 if a.mode == "infer" else 5
+        a.steps = 200 if a.mode == "infer" else 5     # 200 frames = 0.25 s: the two-frame pipeline's fill and drain are < 1 %
     if a.warmup is None:
-        a.warmup = 5 if a.mode == "infer" else 2
+        a.warmup = 8 if a.mode == "infer" else 2
     if a.dtype is None:
         a.dtype = "bf16" if a.mode == "infer" else "fp32"   # the reference trains in fp32
     return a

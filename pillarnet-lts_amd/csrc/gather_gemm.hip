@@ -437,6 +437,10 @@ extern "C" int pn_gather_gemm(const void* in, int cin, int in_ld, long long in_r
   a.free_order = pn_gg_free_order;
   PN_CHECK_ARG(ntaps <= GG_MAX_TAPS, "pn_gather_gemm: at most %d taps", GG_MAX_TAPS);
   {
+    const int rc = pn_gg_try_direct(a, 1, out_fp32 != 0, stream);   // 32 -> 32: no staging at all
+    if (rc != -1) return rc;
+  }
+  {
     const int rc = pn_gg_try_window(a, 1, out_fp32 != 0, stream);   // 3x3 rulebooks: window-staged kernel
     if (rc != -1) return rc;
   }

@@ -63,3 +63,5 @@ static constexpr int GG_MAX_TAPS = 9;
 // gather_gemm_win.hip: returns PN_OK after launching, or -1 when the problem is not eligible
 // (caller falls back to the per-tap kernel).
 int pn_gg_try_window(const GGArgs& a, int groups, bool out_fp32, hipStream_t stream);
+// gather_gemm_direct.hip: the 32 -> 32 level without LDS staging; same return convention
+int pn_gg_try_direct(const GGArgs& a, int groups, bool out_fp32, hipStream_t stream);
