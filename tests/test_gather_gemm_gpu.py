@@ -88,7 +88,7 @@ def test_dense_grid_rulebook(cuda, cin, cout):
     _check(got, reference(x, nbr, w, scale, shift, res, True, rows), rows)
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (256, 256)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (128, 128), (256, 256)])
 def test_sorted_sparse_rulebook_with_device_count(cuda, cin, cout):
     nbr, M = sorted_sparse_rules(90, 700, 0.25, 3, cuda)
     cap = M + 300                                  # capacity > active rows; the count lives on the device
@@ -101,7 +101,7 @@ def test_sorted_sparse_rulebook_with_device_count(cuda, cin, cout):
     assert torch.isnan(got[M:].float()).all()      # rows past the count are not written
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (256, 256), (128, 64)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (256, 256), (128, 64), (32, 32), (32, 64)])
 def test_unsorted_rulebook_takes_gather_mode(cuda, cin, cout):
     """A rulebook without any row locality (random input rows, 30 % missing): every tile's runs exceed the
     window, so the kernel's gather mode must produce the same numbers."""
