@@ -69,6 +69,10 @@ def main():
         nbr = sparse_conv._subm_rules(t, None)
         x = torch.randn((t.capacity, c), device=dev).bfloat16()
         run(f"sparse {name} subm {c}->{c}", x, nbr, t.capacity, t.num_active, c, c)
+    for name, src, cin, cout in (("L1->L2", sp, 32, 64), ("L2->L3", feats["conv2"], 64, 128), ("L3->L4", feats["conv3"], 128, 256)):
+        out_idx, out_num, out_bits, out_rank, nbr, shape, out_cap = sparse_conv._down_rules(src, 2, 1)
+        x = torch.randn((src.capacity, cin), device=dev).bfloat16()
+        run(f"sparse {name} stride 2 {cin}->{cout}", x, nbr, out_cap, out_num, cin, cout)
     c4 = model.backbone.conv4
     with torch.no_grad():
         y = sparse_conv.conv_forward(feats["conv3"], c4[0], c4[1], True)
