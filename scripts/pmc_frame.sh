@@ -6,7 +6,7 @@ rm -rf $OUT; mkdir -p $OUT
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py --steps 5 --warmup 2 > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1 --no-graph > $OUT/p$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
