@@ -564,7 +564,8 @@ static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
 // Tile policy.  0 (default): a launch is alone on the chip, so small levels get small tiles that fill it.
 // 1: the caller keeps several frames in flight on different streams; what counts is CU-time, and a workgroup
 // whose LDS pool stays under 80 KB can share a CU with a workgroup of the other frame's kernel -- 128 x 128 tiles
-// with the 2-deep ring everywhere above 64 outputs.  Same stage order and k-chunking as the default tiles, so
+// with the 2-deep ring on the large levels above 64 outputs, and on the small levels the tile with the least
+// CU-time instead of the one that fills the chip.  Same stage order and k-chunking as the default tiles, so
 // the results are bit-identical under either policy.
 static int g_tile_policy = 0;
 extern "C" int pn_gg_set_tile_policy(int policy) {
@@ -602,12 +603,17 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   }
   // <= 128 outputs: 128 x 128 tiles with a 2-deep weight ring (77 KB, two workgroups per CU): 53.0 -> 50.6 us on the
   // 111 k-row 128 -> 128 level against 256 x 128 tiles that own a CU.  't' = off.
-  if (f == 'T' || ((N <= 128 || shared_cu) && f != 't')) return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
+  const bool small_level = work_rows <= 128 * 160 && N % 128 == 0;
+  if (f == 'T' || ((N <= 128 || (shared_cu && !small_level)) && f != 't')) return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
   if (N <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (work_rows <= 128 * 160 && N % 128 == 0 && f != 'B') {   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
     // 128 x 64 tiles (4 compute waves of 32 x 64 + 4 loaders): as many workgroups as 64 x 128 tiles give, but a
     // workgroup streams half the weight bytes for the same MFMAs (the level is bound by DMA issue): +2 % on the
     // frame.  (WMAX 288: a stride-2 run is 2 * 128 + 3 rows.)  'Q' keeps the 64 x 128 shape for comparison.
+    // sharing the chip with another frame: 256 x 64 tiles -- 128 workgroups on half the CUs, 22 us instead of 19.6,
+    // but a third less CU-time than 256 tiles of 128 x 64 (a tile streams the same weights for twice the rows):
+    // +3 % on the frame with two lanes ('c' = off, 'C' = on without the policy)
+    if (f == 'C' || (shared_cu && f != 'c')) return launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream);
     if (f == 'Q') return launch_win<64, 128, 2, 2, 4, 64, 160, TOut, true>(a, groups, stream);
     return launch_win<128, 64, 4, 1, 4, 64, 288, TOut, true>(a, groups, stream);
   }
