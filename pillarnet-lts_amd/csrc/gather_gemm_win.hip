@@ -597,7 +597,8 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
     // 32-channel chunks change the summation order, so only launches that declare `free_order` (the sparse
     // backbone) take it: the ranked head must reproduce the dense head's bits from another launch shape.
     if (unit && a.cin == 64 && a.free_order && f != 'h') return launch_win<256, 64, 4, 1, 4, 32, 320, TOut, true>(a, groups, stream);
-    if (unit && work_rows <= 256 * 200 && f != 'B') return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
+    // (sharing the chip: the 256-row tiles below take half the workgroups for the same launch time, +1 % on the frame)
+    if (unit && work_rows <= 256 * 200 && f != 'B' && !shared_cu) return launch_win<128, 64, 2, 1, 2, 64, 160, TOut, true>(a, groups, stream);
     return unit ? launch_win<256, 64, 4, 1, 4, 64, 352, TOut, true>(a, groups, stream)
                 : launch_win<256, 64, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   }
