@@ -43,6 +43,7 @@ def parse(argv=None):
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="frames in flight per GPU, one stream each")
+    ap.add_argument("--depth", type=int, default=None, help="frames queued before the host waits for the oldest (default: lanes)")
     ap.add_argument("--no-shared-cu-tiles", action="store_true", help="record the graphs with the one-launch-owns-the-chip tiles")
     ap.add_argument("--no-graph", action="store_true", help="queue every kernel from Python instead of replaying the frame's HIP graph")
     ap.add_argument("--cpu-baseline-1t", action="store_true",
@@ -247,7 +248,7 @@ def run_infer(args):
         # before the host waits for frame i's counts, so the GPU works through the host's hand-over.
         barrier()
         t0 = time.perf_counter()
-        depth = 1 if args.no_graph else args.lanes
+        depth = args.depth if args.depth is not None else (1 if args.no_graph else args.lanes)
         inflight = []
         for i in range(args.steps):
             inflight.append(runner.forward_deferred(examples[i % len(examples)]))
