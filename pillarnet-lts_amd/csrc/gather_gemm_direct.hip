@@ -23,11 +23,13 @@
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #endif
 
-static constexpr int GD_WAVES = 8;          // waves per workgroup; a wave owns 32 consecutive output sites
 static constexpr int GD_PARK_LD = 36;       // floats per parked site row (32 + 4: the rows of a lane group on different banks)
 
-// NB = output channels / 32: the blocks are computed one after the other from the same operand registers
-template <int NB>
+// NB = output channels / 32: the blocks are computed one after the other from the same operand registers.
+// GD_WAVES = waves per workgroup (a wave owns 32 consecutive output sites): 4 for 32 outputs (11.9 against 13.2 us
+// with 8 on the 2 * 10^5-row level: more workgroups per CU), 8 for 64 (18.9 against 21.9: the 36 KB of weights
+// are fetched half as often).
+template <int NB, int GD_WAVES>
 __global__ __launch_bounds__(GD_WAVES * 64, 4) void gg_direct32_kernel(GGArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char wsm[9 * 32 * NB * 64];                  // [tap][cout][cin] bf16, chunks swizzled
@@ -159,11 +161,10 @@ int pn_gg_try_direct(const GGArgs& a, int groups, bool out_fp32, hipStream_t str
   if (a.in_bytes == 0 || a.out_rows != nullptr || a.diag != 0) return -1;
   if ((a.in_ld & 7) != 0 || (a.out_ld & 7) != 0 || (a.residual && (a.res_ld & 7) != 0)) return -1;
   if ((((uintptr_t)a.out | (uintptr_t)a.residual | (uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.wt) & 15) != 0) return -1;
-  const int per_wg = GD_WAVES * 32;
   if (a.cout_total == 32)
-    hipLaunchKernelGGL(gg_direct32_kernel<1>, dim3(pn_div_up(a.rows, per_wg)), dim3(GD_WAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL((gg_direct32_kernel<1, 4>), dim3(pn_div_up(a.rows, 4 * 32)), dim3(4 * 64), 0, stream, a);
   else
-    hipLaunchKernelGGL(gg_direct32_kernel<2>, dim3(pn_div_up(a.rows, per_wg)), dim3(GD_WAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL((gg_direct32_kernel<2, 8>), dim3(pn_div_up(a.rows, 8 * 32)), dim3(8 * 64), 0, stream, a);
   PN_CHECK_LAUNCH("gg_direct32_kernel");
   return PN_OK;
 }
