@@ -154,6 +154,57 @@ class FoldedMLP:
         return x
 
 
+class SparseBlockConv2d(nn.Module):
+    """spconv `SparseConv2d(cin, cout, kernel_size=s, stride=s, bias=True)` as the sparse laterals of
+    BEVStrideFeature use it (bev_interpolation.py:211-218): non-overlapping s x s blocks, an output cell is active
+    iff one of its s * s input cells is.  Weight layout [cout, s, s, cin] (spconv 2.x), as in a checkpoint.
+
+    forward(SparseConvTensor) -> (y [B, cout, H/s, W/s] with the conv + bias at EVERY cell, active [B, H/s, W/s]
+    bool).  The block sum is a dense stride-s convolution of the densified input -- inactive cells are zeros and
+    add nothing -- so it runs on the dense conv kernels; the caller keeps the active cells only."""
+
+    def __init__(self, in_channels, out_channels, block, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.block = in_channels, out_channels, int(block)
+        self.weight = nn.Parameter(torch.empty(out_channels, self.block, self.block, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:
+            bound = 1.0 / (self.block * self.block * in_channels) ** 0.5
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        s = self.block
+        H, W = x.spatial_shape
+        if H % s or W % s:
+            raise NotImplementedError("SparseBlockConv2d: the grid must be a multiple of the block")
+        x = x.exact()                                       # (one host wait: the active cells as an index list)
+        idx = x.indices_cap.long()
+        active = torch.zeros((x.batch_size, H // s, W // s), dtype=torch.bool, device=idx.device)
+        active[idx[:, 0], idx[:, 1] // s, idx[:, 2] // s] = True
+        dense = x.dense().to(self.weight.dtype)
+        y = Fn.conv2d(dense, self.weight.permute(0, 3, 1, 2), self.bias, stride=s)
+        return y, active
+
+
+class SparseLateral(nn.Sequential):
+    """SparseSequential(SparseConv2d(k = stride = s, bias), BatchNorm1d, ReLU) followed by `.dense()`
+    (bev_interpolation.py:211-218, 277-285); children '0', '1', '2' carry the reference's state-dict keys.
+    BatchNorm1d sees the active output cells only, as it does on spconv's feature rows."""
+
+    def __init__(self, in_channels, out_channels, block):
+        super().__init__(SparseBlockConv2d(in_channels, out_channels, block, bias=True),
+                         build_norm_layer(_BN1, out_channels)[1], nn.ReLU())
+
+    def forward(self, x):
+        y, active = self[0](x)
+        rows = y.permute(0, 2, 3, 1)[active]                # [n_active, cout]
+        rows = self[2](self[1](rows)) if rows.shape[0] > 0 else rows
+        out = y.new_zeros(y.shape).permute(0, 2, 3, 1)
+        out[active] = rows.to(out.dtype)
+        return out.permute(0, 3, 1, 2)
+
+
 @SECOND_STAGE.register_module
 class BEVStrideFeature(nn.Module):
     """bev_interpolation.py:162-308: fuse the neck's finest map with backbone stages at `out_stride`,
@@ -177,8 +228,12 @@ class BEVStrideFeature(nn.Module):
             if src not in ("conv1", "conv2", "conv3", "conv4"):
                 continue
             s = backbone_strides[src] / out_stride
-            if s < 1:
-                raise NotImplementedError("sparse lateral convs (kernel = stride > 1) are not built on the HIP path")
+            if s < 1:          # a stage finer than the fused map: block-summing sparse conv (bev_interpolation.py:211-218)
+                self.lat_conv.append(SparseLateral(backbone_channels[src], out_channels, int(np.round(1 / s))))
+                self.lat_conv_name.append(src)
+                self.lat_tensor_type.append("sparse")
+                c_in += out_channels
+                continue
             s = int(s)
             self.lat_conv.append(nn.Sequential(
                 nn.ConvTranspose2d(backbone_channels[src], out_channels, s, stride=s, bias=False),
@@ -193,7 +248,7 @@ class BEVStrideFeature(nn.Module):
 
     def _compile(self, _self=None):
         td = dense_hip.compile_stack(self.top_down_conv)
-        lat = [dense_hip.compile_stack(m) for m in self.lat_conv]
+        lat = [dense_hip.compile_stack(m) if t == "dense" else None for m, t in zip(self.lat_conv, self.lat_tensor_type)]
         return td, lat, dense_hip.compile_stack(self.fusion_conv)
 
     def fused_rows_hip(self, example):
@@ -201,7 +256,7 @@ class BEVStrideFeature(nn.Module):
         the 3x3 fusion conv + bias + BN + ReLU is one launch.  -> Rows [B*H*W, share_channels] bf16."""
         td, lat, fusion = dense_hip.PLANS.get(self, self._compile)
         x = dense_hip.Rows.from_nchw(example["bev_feature"])
-        widths = [td[-1].cout] + [l[-1].cout for l in lat]
+        widths = [td[-1].cout] + [l[-1].cout if l is not None else m[0].out_channels for l, m in zip(lat, self.lat_conv)]
         up = 2 ** sum(isinstance(s, dense_hip.UpStep) for s in td)
         B, H, W = x.B, x.H * up, x.W * up
         cat = torch.empty((B * H * W, sum(widths)), dtype=torch.bfloat16, device=x.t.device)
@@ -209,6 +264,11 @@ class BEVStrideFeature(nn.Module):
         c0 = widths[0]
         for k, src in enumerate(self.lat_conv_name):
             f = example["backbone_features"][src]
+            if lat[k] is None:       # sparse lateral: block conv on the dense kernels, rows copied into the slice
+                y = self.lat_conv[k](f)
+                cat[:, c0:c0 + widths[k + 1]] = dense_hip.Rows.from_nchw(y.to(torch.bfloat16)).t
+                c0 += widths[k + 1]
+                continue
             if isinstance(f, SparseConvTensor):
                 f = f.dense()
             dense_hip.run_stack(lat[k], dense_hip.Rows.from_nchw(f.to(torch.bfloat16)), cat[:, c0:c0 + widths[k + 1]])
@@ -223,6 +283,9 @@ class BEVStrideFeature(nn.Module):
         feats = [self.top_down_conv(cast(example["bev_feature"]))]
         for k, src in enumerate(self.lat_conv_name):
             f = example["backbone_features"][src]
+            if self.lat_tensor_type[k] == "sparse":
+                feats.append(cast(self.lat_conv[k](f)))
+                continue
             if isinstance(f, SparseConvTensor):
                 f = f.dense()
             feats.append(self.lat_conv[k](cast(f)))

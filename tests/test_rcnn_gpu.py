@@ -93,6 +93,66 @@ def test_second_stage_modules_match_reference_outputs(cuda):
         assert d["metadata"] == {"token": i}
 
 
+def test_sparse_lateral_block_convs(cuda):
+    """feature sources finer than out_stride: SparseConv2d(kernel = stride = s) + BN1d + ReLU + dense()
+    (bev_interpolation.py:211-218, 277-285) against a float64 loop over the active cells (spconv is not
+    importable here, so this pins the module to the published block-conv definition, not to the reference)."""
+    from pillarnet_lts_amd.spconv import SparseConvTensor
+    torch.manual_seed(7)
+    rs = np.random.RandomState(7)
+    B, H, W = 2, 32, 48
+    bev = second_stage.BEVStrideFeature(
+        feature_sources=["conv1", "conv2", "conv3"], pillar_size=0.1, pc_range=[0, 0, -2, 4.8, 3.2, 2], out_stride=4,
+        grid_size=5, in_channels=32, share_channels=16, backbone_channels=dict(conv1=8, conv2=16, conv3=128, conv4=256),
+        backbone_strides=dict(conv1=1, conv2=2, conv3=4, conv4=8)).to(cuda).eval()
+    assert bev.lat_tensor_type == ["sparse", "sparse", "dense"]
+    assert bev.lat_conv[0][0].weight.shape == (128, 4, 4, 8) and bev.lat_conv[1][0].weight.shape == (128, 2, 2, 16)
+    for m in bev.modules():                       # non-trivial running statistics
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+
+    def sparse(h, w, c, density):
+        occ = rs.rand(B, h, w) < density
+        idx = np.argwhere(occ).astype(np.int32)                     # ascending (b, y, x)
+        feats = rs.randn(idx.shape[0], c).astype(np.float32)
+        feats[rs.rand(idx.shape[0]) < 0.1] = 0.0                    # active rows whose features are all zero stay active
+        t = SparseConvTensor(torch.from_numpy(feats).to(cuda), torch.from_numpy(idx).to(cuda), (h, w), B)
+        return t, idx, feats
+
+    c1, idx1, f1 = sparse(H, W, 8, 0.15)
+    c2, idx2, f2 = sparse(H // 2, W // 2, 16, 0.3)
+    with torch.no_grad():
+        got = [bev.lat_conv[0](c1).cpu().numpy().astype(np.float64), bev.lat_conv[1](c2).cpu().numpy().astype(np.float64)]
+    for k, (idx, feats, s) in enumerate(((idx1, f1, 4), (idx2, f2, 2))):
+        conv, bn = bev.lat_conv[k][0], bev.lat_conv[k][1]
+        w = conv.weight.detach().cpu().double().numpy()             # [cout, s, s, cin]
+        h, wd = (H, W) if k == 0 else (H // 2, W // 2)
+        acc = np.zeros((B, h // s, wd // s, w.shape[0]))
+        act = np.zeros((B, h // s, wd // s), bool)
+        for (b, y, x), f in zip(idx, feats.astype(np.float64)):
+            acc[b, y // s, x // s] += w[:, y % s, x % s, :] @ f
+            act[b, y // s, x // s] = True
+        acc += conv.bias.detach().cpu().double().numpy()
+        sc = bn.weight.detach().cpu().double().numpy() / np.sqrt(bn.running_var.cpu().double().numpy() + bn.eps)
+        want = np.maximum((acc - bn.running_mean.cpu().double().numpy()) * sc + bn.bias.detach().cpu().double().numpy(), 0)
+        want = np.where(act[..., None], want, 0.0).transpose(0, 3, 1, 2)
+        assert act.sum() > 20 and (~act).sum() > 20
+        np.testing.assert_allclose(got[k], want, atol=2e-4, rtol=1e-4)
+    # the fused map takes them in (fp32 torch path and the bf16 HIP path agree to bf16 precision)
+    ex = dict(rois=torch.from_numpy(_rois(rs, B, 6, 1.5)).to(cuda), bev_feature=torch.randn(B, 32, H // 4, W // 4, device=cuda),
+              backbone_features=dict(conv1=c1, conv2=c2, conv3=torch.randn(B, 128, H // 4, W // 4, device=cuda)))
+    with torch.no_grad():
+        fm = bev.fused_map(ex)
+        assert fm.shape == (B, 16, H // 4, W // 4) and torch.isfinite(fm).all()
+        bev._dense_hip = True
+        ex16 = dict(ex, bev_feature=ex["bev_feature"].bfloat16())
+        fm16 = bev.fused_map(ex16).float()
+    assert (fm16 - fm).abs().max().item() <= 0.05 * max(1.0, fm.abs().max().item())
+
+
 def small_rcnn():
     cfg = presets.waymo_pillarrcnn_fpn()
     rng = [-12.8, -12.8, -2, 12.8, 12.8, 4.0]
