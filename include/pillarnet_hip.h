@@ -439,7 +439,7 @@ int pn_points_in_boxes_2d(const float* boxes, const float* pts, int batch, int b
                           int32_t* box_idx_of_points, pnStream stream);
 
 /* ------------------------------------------------------------------------
- * Multi-sweep merge (the data step in front of the reader; SURVEY 8(f) rank 3).
+ * Multi-sweep merge (the data step in front of the reader).
  * Replaces the nuScenes branch of LoadPointCloudFromFile.__call__ with read_sweep / remove_close
  * (det3d/datasets/pipelines/loading.py:38-61,103-140) for sweeps already resident in HBM:
  *   raw [n_total, raw_dim] fp32 = the .bin files back to back (key sweep first); sweep s owns rows

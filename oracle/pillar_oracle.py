@@ -2,7 +2,7 @@
 imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
 
 Parity status: **unpinned by the reference** for the index part -- the reference ships no test,
-fixture or golden vector for it, and its kernels are CUDA-only (SURVEY.md section 8c).  The
+fixture or golden vector for it, and its kernels are CUDA-only.  The
 arithmetic below follows the reference source line by line; the float->cell step additionally
 restates what `tensor / python_float` does inside torch on a GPU (multiply by the fp32 reciprocal),
 because the reference only ever runs there.  `tests/golden/` pins the pieces that *can* be run from

@@ -8,7 +8,7 @@
 // a linear block (no per-row indices, full 128-B lines), and the three taps kx = 0..2 read their MFMA
 // operand rows out of it through a small per-site row table.  Against staging BM gathered rows per
 // tap this cuts the activation traffic from L2 by ~2.7x (9*BM -> 3*(BM+2) rows per chunk); the
-// per-CU L2 request rate is what bounds the per-tap kernel (DESIGN.md section 4).
+// per-CU L2 request rate is what bounds the per-tap kernel.
 //
 // Per tile the kernel checks that all three runs fit the window (WMAX rows); a tile where one does
 // not (a rulebook without this locality, or neighbouring image rows much denser than the tile's) is

@@ -1,4 +1,4 @@
-"""The data step in front of the reader (SURVEY 8(f) rank 3): multi-sweep loading of a nuScenes frame --
+"""The data step in front of the reader: multi-sweep loading of a nuScenes frame --
 det3d/datasets/pipelines/loading.py:15-61 (read_file / remove_close / read_sweep) and :103-140
 (LoadPointCloudFromFile, NuScenesDataset branch) -- with the merge done on the GPU.
 

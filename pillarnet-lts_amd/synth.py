@@ -1,4 +1,4 @@
-"""Seeded synthetic frames and weights of the shapes BASELINE.json / SURVEY.md section 8(d) name
+"""Seeded synthetic frames and weights of the shapes the benchmark configurations name
 (no dataset or checkpoint is reachable offline).  numpy PCG64 so CPU oracle and GPU path see
 byte-identical inputs."""
 import numpy as np

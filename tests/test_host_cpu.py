@@ -72,7 +72,7 @@ def nusc_model():
 def test_state_dict_contract(nusc_model):
     sd = nusc_model.state_dict()
     n = sum(p.numel() for p in nusc_model.parameters())
-    assert n == 288 + 5307488 + 7936512 + 1522054      # reader + backbone + RPNV1 + CenterHead
+    assert n == 288 + 5307488 + 7936512 + 1522054      # reader + backbone + RPNV1 + CenterHead of the reference's nuScenes PillarNet-18
     shapes = {
         "reader.pfn_layers.shared_mlps.0.weight": (32, 7),
         "reader.pfn_layers.shared_mlps.1.running_var": (32,),

@@ -20,7 +20,7 @@ def load(name):
 
 def test_iou_known_answer_and_matrix_bit_exact():
     g = load("iou3d.npz")
-    assert abs(float(g["known_iou"][0, 0]) - 0.5505213) < 1e-7     # value recorded in SURVEY.md 8(c)
+    assert abs(float(g["known_iou"][0, 0]) - 0.5505213) < 1e-7     # known-answer value of the reference's iou_bev for this pair
     got = iou3d.iou_matrix(g["known_a"], g["known_b"])
     assert got.view(np.uint32)[0, 0] == g["known_iou"].view(np.uint32)[0, 0]
     m = iou3d.iou_matrix(g["boxes_a"], g["boxes_b"])
