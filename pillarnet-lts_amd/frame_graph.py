@@ -82,7 +82,9 @@ class FrameGraphs:
             return None
         torch.cuda.synchronize(dev)
         fr.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fr.graph):
+        # (thread-local error mode: another thread of the process -- a collective library's watchdog polling its
+        # events -- must not invalidate the capture)
+        with torch.cuda.graph(fr.graph, capture_error_mode="thread_local"):
             fr.outs = self._launch(fr.points)
         while len(frames) >= self.max_graphs:
             frames.popitem(last=False)

@@ -64,3 +64,42 @@ def test_frame_graph_replays_match_eager(lanes):
             handles = [graphs.forward_deferred(e) for e in ex2]
             for w, h in zip(want, handles):
                 _same(w, h.result())
+
+
+def test_frame_graph_capture_beside_a_live_process_group():
+    """what every rank of `bench.py --gpus N` does: an RCCL process group (its watchdog thread polling events) is
+    alive while the frame graphs are captured and replayed; collectives before and after still work"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from pillarnet_lts_amd import FrameGraphs, presets, synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        dist.barrier()
+        torch.manual_seed(0)
+        model = presets.build(presets.nusc_pillarnet18())
+        synth.randomize_bn_(model, seed=1)
+        model.to_inference(torch.bfloat16)
+        frames = [torch.from_numpy(synth.nusc_frame(10, 6000, seed=s)).cuda() for s in (21, 22)]
+        exs = [{"points": [f], "metadata": [{"token": i}]} for i, f in enumerate(frames)]
+        graphs = FrameGraphs(model, bucket=8192, lanes=2)
+        with torch.no_grad():
+            want = [model(e, return_loss=False) for e in exs]
+            for rep in range(3):
+                handles = [graphs.forward_deferred(e) for e in exs]
+                dist.all_reduce(t)                       # a collective queued between the replays
+                for w, h in zip(want, handles):
+                    _same(w, h.result())
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert float(t[0]) == 1.0
+    finally:
+        dist.destroy_process_group()
