@@ -1,4 +1,4 @@
-"""One HIP graph per frame shape for PillarNet inference.
+"""One HIP graph per frame shape for PillarNet (and two-stage Pillar R-CNN) inference.
 
 A nuScenes frame is ~75 kernel launches of 2..50 us each; queued from Python one by one they cost the host about as
 long as they cost the GPU.  Every launch of the inference path is sized by capacities known on the host (point
@@ -37,8 +37,10 @@ class FrameGraphs:
         own graphs, so the thin tail of one frame (ranking, NMS: a handful of workgroups) and the latency-bound
         narrow levels share the chip with another frame's kernels.  Frames still finish in order per lane; a
         caller that keeps `lanes` frames in flight (forward_deferred) gets the overlap."""
-        if getattr(model, "compute_dtype", None) != torch.bfloat16 or model.training:
+        first = getattr(model, "single_det", model)          # two-stage detectors wrap the one-stage model
+        if getattr(first, "compute_dtype", None) != torch.bfloat16 or model.training:
             raise ValueError("FrameGraphs needs a model prepared with to_inference(torch.bfloat16)")
+        self.two_stage = first is not model
         self.model, self.bucket, self.max_graphs = model, int(bucket), int(max_graphs)
         self.lanes = []
         for _ in range(int(lanes)):
@@ -64,6 +66,8 @@ class FrameGraphs:
 
     def _launch_frame(self, points):
         m = self.model
+        if self.two_stage:
+            return m.forward_raw(points)
         bev, _ = m.extract_feat(dict(points=points, batch_size=len(points)))
         plan = m.bbox_head.lazy_plan(m.test_cfg)
         if plan is None:
@@ -115,7 +119,7 @@ class FrameGraphs:
         lane.stream.wait_stream(caller)               # the points may have been produced on the caller's stream
         with torch.cuda.stream(lane.stream):
             pending = self._run(lane, key, pts, example)
-        for t in (pending.boxes, pending.scores, pending.labels) if isinstance(pending, PendingDetections) else ():
+        for t in (pending.boxes, pending.scores, pending.labels) if hasattr(pending, "boxes") else ():
             t.record_stream(caller)                   # results are consumed on the caller's stream
         return pending
 
@@ -131,6 +135,9 @@ class FrameGraphs:
             self._fill(fr, pts)
         fr.graph.replay()
         outs = tuple(t.clone() for t in fr.outs)     # the next replay overwrites the graph's own buffers
+        if self.two_stage:
+            from .second_stage import PendingRefined
+            return PendingRefined(example, outs, lambda: m(example, return_loss=False))
         return PendingDetections(m.bbox_head, example, outs, lambda: m(example, return_loss=False))
 
     def __call__(self, example, return_loss=False):

@@ -808,6 +808,42 @@ class PillarRCNN(BaseDetector):
             point_loss, tb = self.point_head.get_loss(tb)
         return self.combine_loss(one_stage_loss, point_loss, roi_loss, tb)
 
+    @torch.no_grad()
+    def forward_raw(self, points):
+        """Inference without a host wait anywhere (what a HIP graph can hold): first stage on the ranked head,
+        RoIs padded on the device (`reorder_first_stage_prediction` with the counts left in device memory),
+        second stage, scores.  -> (boxes [B, N, L], scores [B, N], labels [B, N], keep [B, N] bool, counts + status
+        word of the first stage [B + 1]) with N = NMS_POST_MAXSIZE, or None when the first stage cannot take the
+        ranked head.  `keep` marks the rows forward(example, return_loss=False) returns, in its order."""
+        sd = self.single_det
+        B = len(points)
+        bev, feats = sd.extract_feat(dict(points=points, batch_size=B))
+        plan = sd.bbox_head.lazy_plan(sd.test_cfg) if bev[0].dtype == torch.bfloat16 else None
+        raw = sd.bbox_head.predict_lazy(None, bev, sd.test_cfg, plan, raw=True) if plan is not None else None
+        if raw is None:
+            return None
+        boxes, scores, labels, num = raw
+        N = sd.NMS_POST_MAXSIZE
+        assert boxes.shape[1] == N, (boxes.shape, N)
+        valid = torch.arange(N, device=boxes.device).unsqueeze(0) < num[:B].unsqueeze(1)
+        if self.roi_head.code_size == 9:
+            boxes = boxes[:, :, [0, 1, 2, 3, 4, 5, 8, 6, 7]]
+        example = dict(batch_size=B, metadata=[None] * B, has_class_labels=True, bev_feature=bev[-1], backbone_features=feats,
+                       rois=torch.where(valid.unsqueeze(-1), boxes, boxes.new_zeros(())),
+                       roi_labels=torch.where(valid, labels + 1, labels.new_zeros(())),
+                       roi_scores=torch.where(valid, scores, scores.new_zeros(())))
+        for module in self.second_stage:
+            example = module(example)
+        if self.point_head is not None:
+            example = self.point_head(example)
+        bd = self.roi_head(example, training=False)
+        box, lab = bd["batch_box_preds"], bd["roi_labels"]
+        if box.shape[-1] == 9:
+            box = box[:, :, [0, 1, 2, 3, 4, 5, 7, 8, 6]]
+        score = torch.sqrt(torch.sigmoid(bd["batch_cls_preds"]).view(B, N) * bd["roi_scores"].view(B, N))
+        keep = (lab != 0).view(B, N) & (box[..., 3:6] > 0).all(-1)
+        return box.contiguous(), score, lab.view(B, N) - 1, keep, num
+
     def post_process(self, batch_dict):
         """pillar_rcnn.py:133-166: score = sqrt(sigmoid(cls) * roi_score); no second NMS."""
         out = []
@@ -820,3 +856,34 @@ class PillarRCNN(BaseDetector):
             out.append({"box3d_lidar": box.index_select(0, keep), "scores": score.index_select(0, keep),
                         "label_preds": lab.index_select(0, keep) - 1, "metadata": batch_dict["metadata"][i]})
         return out
+
+
+class PendingRefined:
+    """Two-stage detections of a frame whose kernels are queued but not waited for (the two-stage counterpart of
+    bbox_heads.PendingDetections): result() waits for this frame's first-stage status word, then picks the kept rows."""
+
+    def __init__(self, example, tensors, redo):
+        self.example, self.redo = example, redo
+        self.boxes, self.scores, self.labels, self.keep, num = tensors
+        self.host = torch.empty(num.shape, dtype=num.dtype, pin_memory=True)
+        self.host.copy_(num, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.out = None
+
+    def result(self):
+        if self.out is not None:
+            return self.out
+        self.event.synchronize()
+        B = self.boxes.shape[0]
+        if int(self.host[B]) & 2:            # the first stage's range mask removed ranked cells of an over-full set
+            self.out, self.redo = self.redo(), None
+            return self.out
+        metas = self.example.get("metadata", None) or [None] * B
+        self.out = []
+        for b in range(B):
+            idx = self.keep[b].nonzero().view(-1)
+            self.out.append({"box3d_lidar": self.boxes[b].index_select(0, idx), "scores": self.scores[b].index_select(0, idx),
+                             "label_preds": self.labels[b].index_select(0, idx), "metadata": metas[b]})
+        self.redo = None
+        return self.out

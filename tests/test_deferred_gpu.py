@@ -103,3 +103,26 @@ def test_frame_graph_capture_beside_a_live_process_group():
         assert float(t[0]) == 1.0
     finally:
         dist.destroy_process_group()
+
+
+def test_two_stage_frame_graph_matches_eager():
+    """Pillar R-CNN through FrameGraphs: first stage, device-side RoI padding, second stage and scores in one graph"""
+    from test_rcnn_gpu import small_rcnn
+    from pillarnet_lts_amd import FrameGraphs, presets, synth
+    torch.manual_seed(3)
+    model = presets.build(small_rcnn())
+    synth.randomize_bn_(model, seed=2)
+    model.to_inference(torch.bfloat16)
+    import numpy as np
+    scale = np.array([0.17, 0.17, 1, 1, 1], np.float32)        # the frame squeezed into the small range
+    frames = [torch.from_numpy(synth.waymo_frame(9000, seed=s)[:, :5] * scale).cuda() for s in (31, 32, 33)]
+    frames[1] = frames[1][:7777]
+    exs = [{"points": [f], "metadata": [{"token": i}]} for i, f in enumerate(frames)]
+    graphs = FrameGraphs(model, bucket=4096, lanes=2)
+    with torch.no_grad():
+        want = [model(e, return_loss=False) for e in exs]
+        assert all(w[0]["scores"].shape[0] > 0 for w in want)
+        for rep in range(2):
+            handles = [graphs.forward_deferred(e) for e in exs]
+            for w, h in zip(want, handles):
+                _same(w, h.result())
