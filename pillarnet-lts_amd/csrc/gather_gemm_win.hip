@@ -106,11 +106,11 @@ extern "C" int pn_gg_win_debug_stamps(unsigned long long* host_out, int n) {
 }
 
 // LDS pool = the staging buffers (2 windows + 3 weight tiles), or the parked fp32 output tile if larger
-template <int BM, int BN, int BK, int WMAX, bool UNIT, int RING>
+template <int BM, int BN, int BK, int WMAX, bool UNIT, int RING, int EP = 1>
 constexpr int win_pool_bytes() {
   constexpr int RPP = 1024 / (BK * 2);
   constexpr int staging = 2 * (WMAX + RPP) * BK * 2 + (UNIT ? 6 : RING) * BN * BK * 2;
-  constexpr int parked = BM * (BN * 4 + 16);
+  constexpr int parked = BM / EP * (BN * 4 + 16);      // EP: the tile leaves through the pool in EP passes of BM / EP rows
   return staging > parked ? staging : parked;
 }
 
@@ -121,7 +121,12 @@ constexpr int win_pool_bytes() {
 // ahead; the smaller pool lets two workgroups share a CU and cover each other's barriers instead).
 // NTAPS: 9 (3x3 rulebook: three kernel rows of three taps) or 1 (a plain GEMM over the rows, rulebook optional --
 // the "window" of a tile is then its own BM consecutive rows).
-template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT, int RING, int NTAPS>
+// EP: epilogue passes (the fp32 tile leaves through the pool BM / EP rows at a time).  FUSED (NWL = 0): no loader
+// waves -- every wave issues its share of a stage's DMA pieces at the top of the stage and then computes; with
+// 256 x 256 tiles a workgroup stages 43 pieces per 64 MFMAs per SIMD instead of 38 per 32, which is what the
+// vector issue port of a SIMD is short of (a piece costs it ~150 cycles, an MFMA 8 of its 32).
+template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT, int RING, int NTAPS, int EP,
+          bool FUSED>
 __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a, int force_gather) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no __amdgpu_buffer_rsrc_t to check the helpers against
   constexpr int NWC = NWM * NWN;              // compute waves; waves NWC .. NWC+NWL-1 are loaders
@@ -139,12 +144,14 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   static_assert(!UNIT || NTAPS == 9, "unit stages are a 3x3 notion");
   static_assert(RING == 2 || RING == 3, "weight ring of 2 or 3");
   static_assert(!UNIT || RING == 3, "unit kernels keep the 3-deep ring for their gather-mode tiles");
-  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>();   // staging buffers; the epilogue parks the fp32 tile here
+  constexpr int POOL = win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING, EP>();   // staging buffers; the epilogue parks the fp32 tile here
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
   static_assert(NWM * NWN + NWL >= NG, "one wave per kernel row reduces the rulebook tile");
   static_assert(WMAX % RPP == 0 && BM % RPP == 0 && BN % RPP == 0 && BM <= WMAX, "window geometry");
-  static_assert((BN / RPP) % NWL == 0, "every loader wave must issue the same number of weight pieces");
-  constexpr int NWP = BN / RPP / NWL;         // weight pieces per loader wave and stage
+  constexpr int NLD = FUSED ? NWC : NWL;      // waves that issue DMA
+  static_assert(FUSED == (NWL == 0) && (!FUSED || (!UNIT && RING == 2 && NTAPS == 9)), "fused waves: per-tap stages, 2-deep ring");
+  static_assert((BN / RPP) % NLD == 0, "every loader wave must issue the same number of weight pieces");
+  constexpr int NWP = BN / RPP / NLD;         // weight pieces per loader wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wsm = smem + 2 * ABUF;
   int* const nbr_lds = reinterpret_cast<int*>(smem + POOL);   // [9][BM]
@@ -178,8 +185,8 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   const int lr = lane & 31, lh = lane >> 5;
   const int kchunks = a.cin / BK;
   const int nstages = NTAPS * kchunks;             // stage s = (kernel row g, channel chunk kc, kx t), t fastest
-  const bool loader = wave >= NWC;             // wave-uniform role
-  const int lw = wave - NWC;                   // loader index (pieces are dealt round-robin over NWL)
+  const bool loader = wave >= NWC;             // wave-uniform role (never true with fused waves)
+  const int lw = FUSED ? wave : wave - NWC;    // loader index (pieces are dealt round-robin over NLD)
   GGW_STAMP(wave == 0, 0);
 
   // the rulebook tile and scale / shift first: their round trip (the longest latency of the prologue) runs
@@ -200,18 +207,18 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.wt, 0, (int)((size_t)NTAPS * a.cout_total * a.cin * 2), 0x00020000);
   const unsigned in_row_bytes = (unsigned)a.in_ld * 2u;
-  constexpr int NPA = (WMAX / RPP + NWL - 1) / NWL;   // window pieces per loader wave
+  constexpr int NPA = (WMAX / RPP + NLD - 1) / NLD;   // window pieces per loader wave
   LoaderLanes<NWP, NPA> LL;
   {
     const int lrow = lane / CH, slot = lane % CH;
 #pragma unroll
     for (int j = 0; j < NWP; ++j) {
-      const int r = ((loader ? lw : 0) + j * NWL) * RPP + lrow, n = n0 + r;
+      const int r = ((loader || FUSED ? lw : 0) + j * NLD) * RPP + lrow, n = n0 + r;
       LL.w[j] = n < a.cout_total ? ((unsigned)n * (unsigned)a.cin) * 2u + (unsigned)((slot ^ swz<BK>(r)) << 4) : GG_OOB;
     }
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
-      const int r = ((loader ? lw : 0) + j * NWL) * RPP + lrow;
+      const int r = ((loader || FUSED ? lw : 0) + j * NLD) * RPP + lrow;
       LL.arow[j] = r;
       LL.a[j] = (unsigned)r * in_row_bytes + (unsigned)((slot ^ swz<BK>(r)) << 4);
     }
@@ -219,13 +226,13 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #define WIN_WLOAD_SLOT(s_, slot_)                                                                         \
   do {                                                                                                    \
     const int u_ = (s_) / TPG, g_ = u_ / kchunks;                                                         \
-    win_wload<BK, BN, NWL, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, TPG * g_ + ((s_)-TPG * u_),          \
+    win_wload<BK, BN, NLD, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, TPG * g_ + ((s_)-TPG * u_),          \
                                      u_ - g_ * kchunks, a.cout_total, a.cin, LL);                         \
   } while (0)
 #define WIN_WLOAD(s_) WIN_WLOAD_SLOT(s_, (s_) % RING)
 
   // the weights do not depend on the rulebook: stages 0 and 1 are under way before anything else
-  if (loader) {
+  if (loader || FUSED) {
     WIN_WLOAD(0);
     if (RING == 3 && nstages > 1) WIN_WLOAD(1);
   }
@@ -288,7 +295,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   do {                                                                                                     \
     const int u_ = win ? (f) : (f) / TPG, g_ = u_ / kchunks, kc_ = u_ - g_ * kchunks;                      \
     const int tap_ = win ? 0 : TPG * g_ + ((f)-TPG * u_);                                                  \
-    win_fill<BK, WMAX, BM, NWL, NWP, NPA>(smem + ((f)&1) * ABUF, rs_in, lw, lane, win,                     \
+    win_fill<BK, WMAX, BM, NLD, NWP, NPA>(smem + ((f)&1) * ABUF, rs_in, lw, lane, win,                     \
                                           UNIT_SEL(g_, lo0, lo1, lo2), win ? UNIT_SEL(g_, cnt0, cnt1, cnt2) : BM, \
                                           kc_, nbr_lds + tap_ * BM, in_row_bytes, LL);                     \
   } while (0)
@@ -304,6 +311,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const bool unit_mode = UNIT && win;
+  if constexpr (!FUSED) {
   if (loader) {
     WIN_FILL(0);
     if (unit_mode) {
@@ -438,6 +446,29 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       }
     }
   }
+  } else {
+    // ---- fused waves: a stage's DMA (next stage's weights, and at a fill's first stage the next window) goes out at
+    // the top of the stage, lands under its MFMAs and is waited for at its end
+    const int wm = wave / NWN, wn = wave % NWN;
+    int aoff[3][TM], akey[3][TM];
+    WIN_FILL(0);
+    ROW_TABLE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    GGW_STAMP(wave == 0, 1);
+    for (int s = 0; s < nstages; ++s) {
+      const int f = win ? s / TPG : s;
+      if (s + 1 < nstages) {
+        WIN_WLOAD(s + 1);
+        if ((!win || s - f * TPG == 0) && f + 1 < nfills) WIN_FILL(f + 1);
+      }
+      const char* abase = smem + (f & 1) * ABUF;
+      STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
+      if (s + 1 < nstages) ROW_TABLE(s + 1, 0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
   // the MFMAs sit in opaque asm: the hazard checker does not know that the VALU reads of `acc` below follow them
   // (inside the loop no VALU instruction touches the accumulators)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -448,29 +479,10 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   // output rows -- residual rows are read coalesced here, not 8 bytes per lane from 32 rows.
   TOut* out = reinterpret_cast<TOut*>(a.out);
   constexpr int EROW = BN * 4 + 16;                  // bytes per parked row (+16: rows of a wave on different banks)
-  static_assert((size_t)BM * EROW <= (size_t)POOL, "fp32 tile must fit the staging pool");
+  constexpr int PR = BM / EP;                        // rows per epilogue pass
+  static_assert((size_t)PR * EROW <= (size_t)POOL, "a pass of the fp32 tile must fit the staging pool");
+  static_assert(BM % EP == 0 && PR % WTM == 0, "a compute wave's rows leave in one pass");
   char* et = smem;
-  if (!loader) {
-    const int wm = wave / NWN, wn = wave % NWN;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int rl = wm * WTM + i * 32 + lr;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = wn * WTN + j * 32 + 8 * g + 4 * lh;
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
-          *reinterpret_cast<f32x4*>(et + rl * EROW + cl * 4) = v;   // raw: scale / shift are applied per lane below
-        }
-      }
-    }
-  }
-  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 4);
-  __syncthreads();
-  GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 5);
   // 16-B stores: 8 channels per lane for bf16 (a store instruction costs the same issue time whatever its width)
   constexpr int CPL = sizeof(TOut) == 2 && BN % 8 == 0 ? 8 : 4;   // channels per lane
   constexpr int LPR = BN / CPL;                    // lanes per output row
@@ -485,61 +497,88 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   }
   const bool wide = CPL == 8 && n0 + cl + 8 <= a.cout_total && (a.out_ld & 7) == 0 && (a.res_ld & 7) == 0 &&
                     ((uintptr_t)a.out & 15) == 0 && ((uintptr_t)a.residual & 15) == 0;
-#pragma unroll 8
-  for (int r0 = wave * RPI; r0 < BM; r0 += NW * RPI) {
-    const int rl = r0 + sub, m = m0 + rl;
-    if (!(rl < BM && m < M)) continue;
-    const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
 #pragma unroll
-    for (int h = 0; h < CPL / 4; ++h) {
-      const int c = cl + 4 * h;
-      f32x4 v = *reinterpret_cast<const f32x4*>(et + rl * EROW + c * 4) * sc[h] + sh[h];
-      f32x4 v2 = v;
-      if constexpr (CPL == 8) {
-        if (wide) {   // both halves, one 16-B residual load and one 16-B store
-          if (h == 1) break;
-          v2 = *reinterpret_cast<const f32x4*>(et + rl * EROW + c * 4 + 16) * sc[CPL / 4 - 1] + sh[CPL / 4 - 1];
-          if (a.residual) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.residual + (size_t)m * a.res_ld + n0 + c);
+  for (int ep = 0; ep < EP; ++ep) {
+    if (!loader) {
+      const int wm = wave / NWN, wn = wave % NWN;
+      if ((wm * WTM) / PR == ep) {                   // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] += (float)rv[r]; v2[r] += (float)rv[4 + r]; }
+        for (int i = 0; i < TM; ++i) {
+          const int rl = wm * WTM + i * 32 + lr - ep * PR;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int ccl = wn * WTN + j * 32 + 8 * g + 4 * lh;
+              f32x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+              *reinterpret_cast<f32x4*>(et + rl * EROW + ccl * 4) = v;   // raw: scale / shift are applied per lane below
+            }
           }
-          if (a.relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = fmaxf(v[r], 0.f); v2[r] = fmaxf(v2[r], 0.f); }
-          }
-          bf16x8 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { o[r] = (__bf16)v[r]; o[4 + r] = (__bf16)v2[r]; }
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + c) = o;
-          continue;
         }
       }
-      if (n0 + c >= a.cout_total) continue;
-      if (a.residual) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + n0 + c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      OutOps<TOut>::store4(out + orow * a.out_ld + n0 + c, v);
     }
+    if (ep == 0) GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 4);
+    __syncthreads();
+    if (ep == 0) GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 5);
+#pragma unroll 8
+    for (int r0 = wave * RPI; r0 < PR; r0 += NW * RPI) {
+      const int rp = r0 + sub, rl = rp + ep * PR, m = m0 + rl;
+      if (!(rp < PR && m < M)) continue;
+      const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
+#pragma unroll
+      for (int h = 0; h < CPL / 4; ++h) {
+        const int c = cl + 4 * h;
+        f32x4 v = *reinterpret_cast<const f32x4*>(et + rp * EROW + c * 4) * sc[h] + sh[h];
+        f32x4 v2 = v;
+        if constexpr (CPL == 8) {
+          if (wide) {   // both halves, one 16-B residual load and one 16-B store
+            if (h == 1) break;
+            v2 = *reinterpret_cast<const f32x4*>(et + rp * EROW + c * 4 + 16) * sc[CPL / 4 - 1] + sh[CPL / 4 - 1];
+            if (a.residual) {
+              const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.residual + (size_t)m * a.res_ld + n0 + c);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] += (float)rv[r]; v2[r] += (float)rv[4 + r]; }
+            }
+            if (a.relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] = fmaxf(v[r], 0.f); v2[r] = fmaxf(v2[r], 0.f); }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = (__bf16)v[r]; o[4 + r] = (__bf16)v2[r]; }
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(out) + orow * a.out_ld + n0 + c) = o;
+            continue;
+          }
+        }
+        if (n0 + c >= a.cout_total) continue;
+        if (a.residual) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.residual + (size_t)m * a.res_ld + n0 + c);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        OutOps<TOut>::store4(out + orow * a.out_ld + n0 + c, v);
+      }
+    }
+    if (ep + 1 < EP) __syncthreads();                // the pool is parked into again
   }
   GGW_STAMP(wave == 0, 3);
 #endif
 }
 
 template <int BM, int BN, int NWM, int NWN, int NWL, int BK, int WMAX, typename TOut, bool UNIT = false, int RING = 3,
-          int NTAPS = 9>
+          int NTAPS = 9, int EP = 1, bool FUSED = false>
 static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
   constexpr int NT = (NWM * NWN + NWL) * 64;
-  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING>() + (size_t)NTAPS * BM * 4 + 32 + (size_t)BN * 8;
+  constexpr size_t LDS = (size_t)win_pool_bytes<BM, BN, BK, WMAX, UNIT, RING, EP>() + (size_t)NTAPS * BM * 4 + 32 + (size_t)BN * 8;
   static_assert(LDS <= 160 * 1024, "window kernel LDS budget");
   static const int force_gather = getenv("PN_GG_WIN_GATHER") != nullptr;
-  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT, RING, NTAPS>;
+  auto kern = gg_win_kernel<BM, BN, NWM, NWN, NWL, BK, WMAX, TOut, UNIT, RING, NTAPS, EP, FUSED>;
   static bool attr_set = false;
   if (!attr_set && LDS > 32 * 1024) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
@@ -605,6 +644,12 @@ static int dispatch_win(const GGArgs& a, int groups, hipStream_t stream) {
   // <= 128 outputs: 128 x 128 tiles with a 2-deep weight ring (77 KB, two workgroups per CU): 53.0 -> 50.6 us on the
   // 111 k-row 128 -> 128 level against 256 x 128 tiles that own a CU.  't' = off.
   const bool small_level = work_rows <= 128 * 160 && N % 128 == 0;
+  const long long in_rows = a.in_ld > 0 ? (long long)a.in_bytes / (2ll * a.in_ld) : 0;
+  const bool same_grid = in_rows <= (long long)a.rows + a.rows / 4;     // stride 1: as many input rows as output sites
+  // sharing the chip: 256 x 256 tiles on fused waves take half the CUs for 1.5x the launch time of the 128 x 256
+  // tiles (a quarter less CU-time); the other frame's kernels run on the rest ('f' = off, 'F' = on without the policy)
+  if ((f == 'F' || (shared_cu && f != 'f')) && N > 128 && !small_level && same_grid)
+    return launch_win<256, 256, 4, 2, 0, 64, 264, TOut, false, 2, 9, 2, true>(a, groups, stream);
   if (f == 'T' || ((N <= 128 || (shared_cu && !small_level)) && f != 't')) return launch_win<128, 128, 2, 2, 4, 64, 144, TOut, false, 2>(a, groups, stream);
   if (N <= 128) return launch_win<256, 128, 4, 1, 4, 64, 352, TOut>(a, groups, stream);
   if (work_rows <= 128 * 160 && N % 128 == 0 && f != 'B') {   // (WMAX 160: a stride-2 run is 2 * 64 + 3 rows)
