@@ -458,15 +458,17 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     GGW_STAMP(wave == 0, 1);
     for (int s = 0; s < nstages; ++s) {
       const int f = win ? s / TPG : s;
-      if (s + 1 < nstages) {
-        WIN_WLOAD(s + 1);
-        if ((!win || s - f * TPG == 0) && f + 1 < nfills) WIN_FILL(f + 1);
-      }
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
+      if ((!win || s - f * TPG == 0) && f + 1 < nfills) WIN_FILL(f + 1);
+      if (s + 1 < nstages) WIN_WLOAD(s + 1);
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // DMA issued
       const char* abase = smem + (f & 1) * ABUF;
       STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
       if (s + 1 < nstages) ROW_TABLE(s + 1, 0);
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
     }
   }
   // the MFMAs sit in opaque asm: the hazard checker does not know that the VALU reads of `acc` below follow them
