@@ -41,7 +41,9 @@ struct LoaderLanes {
 // the run are skipped: stale LDS there is never addressed).  Gather mode (slow path): the BM rows
 // nbr_row[0..BM).  Lane l of a piece fills slot l%CH of row l/CH and fetches chunk (slot ^ swizzle(row))
 // of the source row, so the LDS image stays linear and the MFMA operand reads are bank-conflict free.
-template <int BK, int WMAX, int BM, int NW, int NPW, int NPA>
+// ALL: every wave issues exactly NPA pieces (a piece past the run re-zeroes the zero rows), so that a counted
+// `s_waitcnt vmcnt(NPA)` can leave a window fill in flight across a barrier.
+template <int BK, int WMAX, int BM, int NW, int NPW, int NPA, bool ALL = false>
 __device__ __forceinline__ void win_fill(char* base, __amdgpu_buffer_rsrc_t rs_in, int wave, int lane, bool win,
                                          int lo, int cnt, int kc, const int* nbr_row, unsigned in_row_bytes,
                                          const LoaderLanes<NPW, NPA>& L) {
@@ -51,7 +53,15 @@ __device__ __forceinline__ void win_fill(char* base, __amdgpu_buffer_rsrc_t rs_i
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
       const int piece = wave + j * NW;
-      if (piece * RPP >= cnt) break;
+      if (piece * RPP >= cnt) {
+        if constexpr (ALL) {   // out-of-range source: zeros land on the (always zero) rows behind the window
+          auto lds0 = (__attribute__((address_space(3))) void*)(base + WMAX * ROWB);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds0, 16, GG_OOB, 0, 0, 0);
+          continue;
+        } else {
+          break;
+        }
+      }
       const unsigned off = L.arow[j] < cnt ? L.a[j] : GG_OOB;
       auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, soff, 0, 0);
@@ -148,7 +158,10 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
   static_assert(NWM * NWN + NWL >= NG, "one wave per kernel row reduces the rulebook tile");
   static_assert(WMAX % RPP == 0 && BM % RPP == 0 && BN % RPP == 0 && BM <= WMAX, "window geometry");
-  constexpr int NLD = FUSED ? NWC : NWL;      // waves that issue DMA
+  // waves that issue DMA.  Fused: one of the two waves of every SIMD (waves 0-3) stages for both -- its partner's MFMAs
+  // run under the issue burst, its own MFMAs under the partner's wait; with all eight issuing at the top of a stage
+  // the bursts of a SIMD's two waves add up in front of the MFMAs of both (3 560 against 2 300 cycles per stage)
+  constexpr int NLD = FUSED ? 4 : NWL;
   static_assert(FUSED == (NWL == 0) && (!FUSED || (!UNIT && RING == 2 && NTAPS == 9)), "fused waves: per-tap stages, 2-deep ring");
   static_assert((BN / RPP) % NLD == 0, "every loader wave must issue the same number of weight pieces");
   constexpr int NWP = BN / RPP / NLD;         // weight pieces per loader wave and stage
@@ -232,7 +245,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
 #define WIN_WLOAD(s_) WIN_WLOAD_SLOT(s_, (s_) % RING)
 
   // the weights do not depend on the rulebook: stages 0 and 1 are under way before anything else
-  if (loader || FUSED) {
+  if (loader || (FUSED && wave < NLD)) {
     WIN_WLOAD(0);
     if (RING == 3 && nstages > 1) WIN_WLOAD(1);
   }
@@ -295,7 +308,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   do {                                                                                                     \
     const int u_ = win ? (f) : (f) / TPG, g_ = u_ / kchunks, kc_ = u_ - g_ * kchunks;                      \
     const int tap_ = win ? 0 : TPG * g_ + ((f)-TPG * u_);                                                  \
-    win_fill<BK, WMAX, BM, NLD, NWP, NPA>(smem + ((f)&1) * ABUF, rs_in, lw, lane, win,                     \
+    win_fill<BK, WMAX, BM, NLD, NWP, NPA, FUSED>(smem + ((f)&1) * ABUF, rs_in, lw, lane, win,              \
                                           UNIT_SEL(g_, lo0, lo1, lo2), win ? UNIT_SEL(g_, cnt0, cnt1, cnt2) : BM, \
                                           kc_, nbr_lds + tap_ * BM, in_row_bytes, LL);                     \
   } while (0)
@@ -451,7 +464,8 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     // the top of the stage, lands under its MFMAs and is waited for at its end
     const int wm = wave / NWN, wn = wave % NWN;
     int aoff[3][TM], akey[3][TM];
-    WIN_FILL(0);
+    const bool stager = wave < NLD;
+    if (stager) WIN_FILL(0);
     ROW_TABLE(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -459,14 +473,18 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     for (int s = 0; s < nstages; ++s) {
       const int f = win ? s / TPG : s;
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
-      if ((!win || s - f * TPG == 0) && f + 1 < nfills) WIN_FILL(f + 1);
-      if (s + 1 < nstages) WIN_WLOAD(s + 1);
+      const bool fill_now = (!win || s - f * TPG == 0) && f + 1 < nfills;
+      if (stager) {
+        if (s + 1 < nstages) WIN_WLOAD(s + 1);
+        if (fill_now) WIN_FILL(f + 1);   // issued last: a window (needed three stages on) stays in flight over this barrier
+      }
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // DMA issued
       const char* abase = smem + (f & 1) * ABUF;
       STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
       if (s + 1 < nstages) ROW_TABLE(s + 1, 0);
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (fill_now && win) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
     }
