@@ -126,3 +126,24 @@ def test_two_stage_frame_graph_matches_eager():
             handles = [graphs.forward_deferred(e) for e in exs]
             for w, h in zip(want, handles):
                 _same(w, h.result())
+
+
+def test_frame_graph_degenerate_frames():
+    """an empty frame, a frame with every point out of range and a one-point frame replay a graph captured on an
+    ordinary frame of the same bucket (row counts of 0 reach every kernel of the graph)"""
+    from pillarnet_lts_amd import FrameGraphs, presets, synth
+    torch.manual_seed(0)
+    model = presets.build(presets.nusc_pillarnet18())
+    synth.randomize_bn_(model, seed=1)
+    model.to_inference(torch.bfloat16)
+    graphs = FrameGraphs(model, bucket=8192, lanes=2)
+    full = torch.from_numpy(synth.nusc_frame(1, 6000, seed=41)).cuda()
+    frames = [full, full[:0], torch.full((50, 5), 400.0, device="cuda"),
+              torch.tensor([[0.1, 0.2, -1.0, 3.0, 0.0]], device="cuda"), full]
+    with torch.no_grad():
+        for i, f in enumerate(frames):
+            ex = {"points": [f], "metadata": [{"token": i}]}
+            want = model(ex, return_loss=False)
+            for rep in range(2):                      # once per lane
+                _same(want, graphs(ex))
+        assert sorted({k for ln in graphs.lanes for k in ln.frames}) == [(5, (8192,))]
