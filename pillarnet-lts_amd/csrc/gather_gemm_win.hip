@@ -96,19 +96,28 @@ __device__ __forceinline__ void win_wload(char* base, __amdgpu_buffer_rsrc_t rs_
   }
 }
 
-// diag == 4: s_memtime stamps of workgroup 0 (tuning aid; read with pn_gg_win_debug_stamps):
+// diag == 4 + 16 * b: s_memtime stamps of workgroup (b, 0) (tuning aid; read with pn_gg_win_debug_stamps):
 // [0..3] kernel start / prologue done / main loop done / end (compute wave 0); then per stage 4 slots:
 // compute wave 0 {stage start, MFMAs done, barrier passed}, loader wave 0 {ready for the barrier};
 // then 8 prologue / epilogue marks
 static constexpr int GGW_STAMP_STAGES = 40;
 __device__ unsigned long long ggw_stamps[4 + GGW_STAMP_STAGES * 4 + 8];
+// (the same mode records every workgroup's start and end tick, to see how a launch's workgroups overlap in time)
+static constexpr int GGW_SPAN_BLOCKS = 2048;
+__device__ unsigned long long ggw_spans[GGW_SPAN_BLOCKS * 2];
 #define GGW_STAMP(cond, idx)                                                    \
   do {                                                                          \
-    if (a.diag == 4 && blockIdx.x == 0 && blockIdx.y == 0 && (cond)) {          \
+    if ((a.diag & 15) == 4 && (cond)) {                                         \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
-      if (lane == 0) ggw_stamps[(idx)] = t_;                                    \
+      if ((int)blockIdx.x == (a.diag >> 4) && blockIdx.y == 0 && lane == 0) ggw_stamps[(idx)] = t_; \
+      const int lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      if (((idx) == 0 || (idx) == 3) && lb_ < GGW_SPAN_BLOCKS && lane == 0) ggw_spans[2 * lb_ + ((idx) == 3)] = t_; \
     }                                                                           \
   } while (0)
+extern "C" int pn_gg_win_debug_spans(unsigned long long* host_out, int n) {
+  if (n > GGW_SPAN_BLOCKS * 2) n = GGW_SPAN_BLOCKS * 2;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ggw_spans), (size_t)n * 8);
+}
 extern "C" int pn_gg_win_debug_stamps(unsigned long long* host_out, int n) {
   const int total = 4 + GGW_STAMP_STAGES * 4 + 8;
   if (n > total) n = total;

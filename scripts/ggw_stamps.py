@@ -1,7 +1,7 @@
 """s_memtime stamps of the window gather-GEMM (PN_GG_DIAG=4) on one dense layer shape."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PN_GG_DIAG"] = "4"
+os.environ["PN_GG_DIAG"] = str(4 + 16 * int(sys.argv[4]) if len(sys.argv) > 4 else 4)      # argv[4]: which row tile to stamp
 import numpy as np, torch
 from scripts.gg_bench import grid_rules, run, dev
 from pillarnet_lts_amd import _lib
@@ -23,3 +23,32 @@ print(f"per stage: compute {np.mean(a[:,1]-a[:,0]):.0f}  barrier wait {np.mean(a
       f"stage {np.mean(st[3:nst-2,0]-st[2:nst-3,0]):.0f}  loader 0 landed (ready for barrier) at +{np.mean(a[:,3]-a[:,0]):.0f}")
 print(f"prologue: loads issued +{x[0]-k[0]}  nbr in LDS/atomics +{x[1]-k[0]}  after barrier +{x[2]-k[0]}  row table +{x[3]-k[0]}  loop start +{k[1]-k[0]}")
 print(f"epilogue: parked +{x[4]-k[2]}  after sync +{x[5]-k[2]}  stores issued +{k[3]-k[2]}")
+
+# every workgroup's start / end tick: how the launch's workgroups overlap (ticks of different XCDs may be offset, so
+# spans are taken per XCD: workgroup i runs on XCD i % 8)
+nb = int(os.environ.get("GGW_BLOCKS", "0"))
+if nb:
+    sp = (ctypes.c_ulonglong * (2 * nb))()
+    L.pn_gg_win_debug_spans(sp, 2 * nb)
+    s = np.frombuffer(sp, dtype=np.uint64).astype(np.int64).reshape(nb, 2)
+    dur = s[:, 1] - s[:, 0]
+    print(f"workgroups {nb}: duration min {dur.min()}  median {int(np.median(dur))}  max {dur.max()}")
+    for xcd in range(8):
+        q = s[xcd::8]
+        st = np.sort(q[:, 0] - q[:, 0].min())
+        print(f"  xcd {xcd}: {len(q)} workgroups, span {q[:,1].max() - q[:,0].min()} ticks; start offsets: median {int(np.median(st))}  "
+              f"90% {int(st[int(0.9 * (len(st) - 1))])}  last {st[-1]}")
+    if os.environ.get("GGW_DETAIL"):
+        gx = int(os.environ["GGW_DETAIL"])          # grid x (row tiles)
+        print("  deciles:", [int(np.percentile(dur, p)) for p in range(0, 101, 10)])
+        print("  mean by i % 8:", [int(dur[k::8].mean()) for k in range(8)])
+        print("  mean by i % 32:", [int(dur[k::32].mean()) for k in range(32)])
+        ny = nb // gx
+        for y in range(ny):
+            d = dur[y * gx:(y + 1) * gx]
+            print(f"  column tile {y}: mean {int(d.mean())}; by row-tile eighths:", [int(c.mean()) for c in np.array_split(d, 8)])
+        slow = np.argsort(-dur)[:24]
+        print("  slowest:", [(int(i % gx), int(i // gx), int(dur[i])) for i in slow])
+        # start order: who starts late (ticks are comparable only inside an XCD; print raw starts relative to the global minimum modulo 2^20 to spot groups)
+        st = s[:, 0]
+        print("  start tick spread (max - min):", int(st.max() - st.min()))
