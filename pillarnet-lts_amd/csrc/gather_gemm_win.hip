@@ -114,6 +114,22 @@ __device__ unsigned long long ggw_spans[GGW_SPAN_BLOCKS * 2];
       if (((idx) == 0 || (idx) == 3) && lb_ < GGW_SPAN_BLOCKS && lane == 0) ggw_spans[2 * lb_ + ((idx) == 3)] = t_; \
     }                                                                           \
   } while (0)
+// (and, for the stamped workgroup, every wave's arrival at / departure from the stage barrier of stages
+// GGW_WAVE_S0 .. +3 in the per-tap loop: [wave][stage][arrive, leave, stage start])
+static constexpr int GGW_WAVE_S0 __attribute__((unused)) = 8;
+__device__ unsigned long long ggw_wave[16 * 4 * 3];
+#define GGW_WSTAMP(s_, which)                                                                  \
+  do {                                                                                         \
+    if ((a.diag & 15) == 4 && (int)blockIdx.x == (a.diag >> 4) && blockIdx.y == 0 && (s_) >= GGW_WAVE_S0 && \
+        (s_) < GGW_WAVE_S0 + 4 && wave < 16) {                                                 \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                              \
+      if (lane == 0) ggw_wave[(wave * 4 + ((s_)-GGW_WAVE_S0)) * 3 + (which)] = t_;             \
+    }                                                                                          \
+  } while (0)
+extern "C" int pn_gg_win_debug_waves(unsigned long long* host_out, int n) {
+  if (n > 16 * 4 * 3) n = 16 * 4 * 3;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ggw_wave), (size_t)n * 8);
+}
 extern "C" int pn_gg_win_debug_spans(unsigned long long* host_out, int n) {
   if (n > GGW_SPAN_BLOCKS * 2) n = GGW_SPAN_BLOCKS * 2;
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ggw_spans), (size_t)n * 8);
@@ -366,7 +382,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
           if (RING == 3 && s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           GGW_STAMP(lw == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // loader 0 ready for the barrier
+          GGW_WSTAMP(s, 0);
           __builtin_amdgcn_s_barrier();
+          GGW_WSTAMP(s, 1);
         }
       }
     }
@@ -392,7 +410,10 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     // once per k-step, ~500 of a stage's 1600 cycles, and sched_group_barrier made it chain MFMAs on one
     // accumulator).  Fragments are double-buffered: the reads of step ks+1 go out two per MFMA behind the
     // first MFMAs of step ks and are waited for (lgkmcnt counts only what this block issued) at the top of
-    // step ks+1.
+    // step ks+1.  A wave tile of one or two MFMAs per k-step has no such cover: there all reads of step ks+1 go
+    // out before the first MFMA of step ks (128 x 64 tiles on a 90 x 90 map: 19.1 -> 16.1 us, the 16-output
+    // heat-map conv 23.5 -> 20.5; on four or more MFMAs per k-step the same order costs 5-8 registers and is
+    // 0-5 % slower).
 #define STAGE_MFMA(abase_, wbase_, slot_)                                                                  \
   do {                                                                                                     \
     const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(abase_);      \
@@ -414,6 +435,12 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                               \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
       int nxt = 0;                                                                                         \
+      if (TM * TN <= 2 && ks + 1 < BK / 16) {                                                           \
+        _Pragma("unroll") for (; nxt < TM + TN; ++nxt) {                                                   \
+          if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], ks + 1);                     \
+          else DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], ks + 1);               \
+        }                                                                                                  \
+      }                                                                                                    \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {      \
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                                             \
                      : "+v"(acc[i][j])                                                                     \
@@ -456,6 +483,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       GGW_STAMP(wave == 0, 1);
       for (int s = 0; s < nstages; ++s) {
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
+        GGW_WSTAMP(s, 2);
         const char* abase = smem + ((win ? s / TPG : s) & 1) * ABUF;
         if (a.diag != 1) {
           STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
@@ -463,7 +491,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         if (s + 1 < nstages) ROW_TABLE(s + 1, 0);   // static rulebook tile: next stage's rows before the barrier
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GGW_WSTAMP(s, 0);
         __builtin_amdgcn_s_barrier();
+        GGW_WSTAMP(s, 1);
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
       }
     }

@@ -52,3 +52,13 @@ if nb:
         # start order: who starts late (ticks are comparable only inside an XCD; print raw starts relative to the global minimum modulo 2^20 to spot groups)
         st = s[:, 0]
         print("  start tick spread (max - min):", int(st.max() - st.min()))
+
+if os.environ.get("GGW_WAVES"):
+    wb = (ctypes.c_ulonglong * (16 * 4 * 3))()
+    L.pn_gg_win_debug_waves(wb, 16 * 4 * 3)
+    w = np.frombuffer(wb, dtype=np.uint64).astype(np.int64).reshape(16, 4, 3)
+    print("per wave, stages 8..11 of the per-tap loop: arrival at / departure from the stage barrier relative to the earliest stage start")
+    for st in range(4):
+        starts = w[:, st, 2]
+        t0 = starts[starts > 0].min() if (starts > 0).any() else w[:, st, 0][w[:, st, 0] > 0].min()
+        print(f"  stage {8 + st}: " + "  ".join(f"w{i}:{w[i, st, 0] - t0}/{w[i, st, 1] - t0}" for i in range(16) if w[i, st, 0] > 0))
