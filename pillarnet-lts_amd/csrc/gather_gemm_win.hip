@@ -96,7 +96,8 @@ __device__ __forceinline__ void win_wload(char* base, __amdgpu_buffer_rsrc_t rs_
   }
 }
 
-// diag == 4 + 16 * b: s_memtime stamps of workgroup (b, 0) (tuning aid; read with pn_gg_win_debug_stamps):
+// Probe builds only (-DGGW_STAMPS, scripts/build_probe_lib.sh; the shipped kernels carry no stamp code).
+// diag == 4 + 16 * b: s_memtime stamps of workgroup (b, 0) (read with pn_gg_win_debug_stamps):
 // [0..3] kernel start / prologue done / main loop done / end (compute wave 0); then per stage 4 slots:
 // compute wave 0 {stage start, MFMAs done, barrier passed}, loader wave 0 {ready for the barrier};
 // then 8 prologue / epilogue marks
@@ -105,6 +106,7 @@ __device__ unsigned long long ggw_stamps[4 + GGW_STAMP_STAGES * 4 + 8];
 // (the same mode records every workgroup's start and end tick, to see how a launch's workgroups overlap in time)
 static constexpr int GGW_SPAN_BLOCKS = 2048;
 __device__ unsigned long long ggw_spans[GGW_SPAN_BLOCKS * 2];
+#ifdef GGW_STAMPS
 #define GGW_STAMP(cond, idx)                                                    \
   do {                                                                          \
     if ((a.diag & 15) == 4 && (cond)) {                                         \
@@ -114,10 +116,14 @@ __device__ unsigned long long ggw_spans[GGW_SPAN_BLOCKS * 2];
       if (((idx) == 0 || (idx) == 3) && lb_ < GGW_SPAN_BLOCKS && lane == 0) ggw_spans[2 * lb_ + ((idx) == 3)] = t_; \
     }                                                                           \
   } while (0)
+#else
+#define GGW_STAMP(cond, idx) do {} while (0)
+#endif
 // (and, for the stamped workgroup, every wave's arrival at / departure from the stage barrier of stages
 // GGW_WAVE_S0 .. +3 in the per-tap loop: [wave][stage][arrive, leave, stage start])
 static constexpr int GGW_WAVE_S0 __attribute__((unused)) = 8;
-__device__ unsigned long long ggw_wave[16 * 4 * 3];
+__device__ unsigned long long ggw_wave[16 * 4 * 3 + 16 * 4];
+#ifdef GGW_STAMPS
 #define GGW_WSTAMP(s_, which)                                                                  \
   do {                                                                                         \
     if ((a.diag & 15) == 4 && (int)blockIdx.x == (a.diag >> 4) && blockIdx.y == 0 && (s_) >= GGW_WAVE_S0 && \
@@ -126,8 +132,25 @@ __device__ unsigned long long ggw_wave[16 * 4 * 3];
       if (lane == 0) ggw_wave[(wave * 4 + ((s_)-GGW_WAVE_S0)) * 3 + (which)] = t_;             \
     }                                                                                          \
   } while (0)
+#else
+#define GGW_WSTAMP(s_, which) do {} while (0)
+#endif
+// -DGGW_KSTAMPS (probe build only): the tick at which each k-step of stage GGW_WAVE_S0 + 2 starts (fragments
+// landed), per wave of the stamped workgroup, behind the barrier stamps
+#ifdef GGW_KSTAMPS
+#define GGW_KSTAMP(ks_)                                                                        \
+  do {                                                                                         \
+    if ((a.diag & 15) == 4 && (int)blockIdx.x == (a.diag >> 4) && blockIdx.y == 0 && kstamp_stage == GGW_WAVE_S0 + 2 && \
+        wave < 16 && (ks_) < 4) {                                                              \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                              \
+      if (lane == 0) ggw_wave[16 * 4 * 3 + wave * 4 + (ks_)] = t_;                             \
+    }                                                                                          \
+  } while (0)
+#else
+#define GGW_KSTAMP(ks_) do {} while (0)
+#endif
 extern "C" int pn_gg_win_debug_waves(unsigned long long* host_out, int n) {
-  if (n > 16 * 4 * 3) n = 16 * 4 * 3;
+  if (n > 16 * 4 * 3 + 16 * 4) n = 16 * 4 * 3 + 16 * 4;
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ggw_wave), (size_t)n * 8);
 }
 extern "C" int pn_gg_win_debug_spans(unsigned long long* host_out, int n) {
@@ -349,6 +372,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const bool unit_mode = UNIT && win;
+#ifdef GGW_KSTAMPS
+  int kstamp_stage = -1;
+#endif
   if constexpr (!FUSED) {
   if (loader) {
     WIN_FILL(0);
@@ -434,6 +460,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     _Pragma("unroll") for (int j = 0; j < TN; ++j) DS_READ_FRAG(fw[0][j], rw[j], kw[j], 0);                \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                               \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+      GGW_KSTAMP(ks);                                                                                      \
       int nxt = 0;                                                                                         \
       if (TM * TN <= 2 && ks + 1 < BK / 16) {                                                           \
         _Pragma("unroll") for (; nxt < TM + TN; ++nxt) {                                                   \
@@ -484,6 +511,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       for (int s = 0; s < nstages; ++s) {
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
         GGW_WSTAMP(s, 2);
+#ifdef GGW_KSTAMPS
+        kstamp_stage = s;
+#endif
         const char* abase = smem + ((win ? s / TPG : s) & 1) * ABUF;
         if (a.diag != 1) {
           STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);

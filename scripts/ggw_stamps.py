@@ -1,4 +1,5 @@
-"""s_memtime stamps of the window gather-GEMM (PN_GG_DIAG=4) on one dense layer shape."""
+"""s_memtime stamps of the window gather-GEMM (PN_GG_DIAG=4) on one dense layer shape.  Needs the probe build of the
+library (scripts/build_probe_lib.sh, PN_LIB_PATH=.../scripts/ab/stamps.so): the shipped kernels carry no stamp code."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PN_GG_DIAG"] = str(4 + 16 * int(sys.argv[4]) if len(sys.argv) > 4 else 4)      # argv[4]: which row tile to stamp
@@ -54,11 +55,18 @@ if nb:
         print("  start tick spread (max - min):", int(st.max() - st.min()))
 
 if os.environ.get("GGW_WAVES"):
-    wb = (ctypes.c_ulonglong * (16 * 4 * 3))()
-    L.pn_gg_win_debug_waves(wb, 16 * 4 * 3)
-    w = np.frombuffer(wb, dtype=np.uint64).astype(np.int64).reshape(16, 4, 3)
+    wb = (ctypes.c_ulonglong * (16 * 4 * 3 + 16 * 4))()
+    L.pn_gg_win_debug_waves(wb, 16 * 4 * 3 + 16 * 4)
+    wall = np.frombuffer(wb, dtype=np.uint64).astype(np.int64)
+    w, ksteps = wall[:192].reshape(16, 4, 3), wall[192:].reshape(16, 4)
     print("per wave, stages 8..11 of the per-tap loop: arrival at / departure from the stage barrier relative to the earliest stage start")
     for st in range(4):
         starts = w[:, st, 2]
         t0 = starts[starts > 0].min() if (starts > 0).any() else w[:, st, 0][w[:, st, 0] > 0].min()
         print(f"  stage {8 + st}: " + "  ".join(f"w{i}:{w[i, st, 0] - t0}/{w[i, st, 1] - t0}" for i in range(16) if w[i, st, 0] > 0))
+    if os.environ.get("GGW_KSTEPS"):     # library built with -DGGW_KSTAMPS
+        starts = w[:, 2, 2]
+        t0 = starts[starts > 0].min()
+        print("  stage 10, k-step starts (fragments landed) per compute wave, then arrival at the barrier:")
+        for i in range(8):
+            print(f"    w{i}: stage start {w[i, 2, 2] - t0}  k-steps {[int(v - t0) for v in ksteps[i]]}  barrier {w[i, 2, 0] - t0}")
