@@ -106,6 +106,13 @@ __device__ unsigned long long ggw_stamps[4 + GGW_STAMP_STAGES * 4 + 8];
 // (the same mode records every workgroup's start and end tick, to see how a launch's workgroups overlap in time)
 static constexpr int GGW_SPAN_BLOCKS = 2048;
 __device__ unsigned long long ggw_spans[GGW_SPAN_BLOCKS * 2];
+// (likewise the probes that drop the MFMAs, diag 1, or the staging, diag 2: a scalar branch per stage costs the
+// stage loop ~20 cycles)
+#ifdef GGW_STAMPS
+#define GGW_DIAG(x) (a.diag == (x))
+#else
+#define GGW_DIAG(x) false
+#endif
 #ifdef GGW_STAMPS
 #define GGW_STAMP(cond, idx)                                                    \
   do {                                                                          \
@@ -362,6 +369,24 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   } while (0)
   const int spf = win ? TPG : 1;               // stages per fill
   const int nfills = nstages / spf;
+  // A stage's coordinates (t = tap inside the kernel row, kc = channel chunk, g = kernel row; t fastest) are
+  // advanced, not derived from the stage index: the divisions by 3 and by the chunk count cost a wave ~25 scalar
+  // instructions per stage, in front of the barrier every other wave waits at.
+#define STAGE_NEXT(t1_, kc1_, g1_, t0_, kc0_, g0_)   \
+  int t1_ = (t0_) + 1, kc1_ = (kc0_), g1_ = (g0_);    \
+  if (t1_ == TPG) {                                   \
+    t1_ = 0;                                          \
+    if (++kc1_ == kchunks) {                          \
+      kc1_ = 0;                                       \
+      ++g1_;                                          \
+    }                                                 \
+  }
+#define WIN_WLOAD_AT(slot_, g_, kc_, t_) \
+  win_wload<BK, BN, NLD, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, TPG * (g_) + (t_), (kc_), a.cout_total, a.cin, LL)
+#define WIN_FILL_AT(par_, g_, kc_, t_)                                                                       \
+  win_fill<BK, WMAX, BM, NLD, NWP, NPA, FUSED>(smem + (par_) * ABUF, rs_in, lw, lane, win,                   \
+                                               UNIT_SEL(g_, lo0, lo1, lo2), win ? UNIT_SEL(g_, cnt0, cnt1, cnt2) : BM, \
+                                               (kc_), nbr_lds + (win ? 0 : TPG * (g_) + (t_)) * BM, in_row_bytes, LL)
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -385,7 +410,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       for (int u = 0; u < nfills; ++u) {
-        if (u + 1 < nfills && a.diag != 2) {
+        if (u + 1 < nfills && !GGW_DIAG(2)) {
           WIN_FILL(u + 1);
 #pragma unroll
           for (int t = 0; t < 3; ++t) WIN_WLOAD_SLOT(3 * (u + 1) + t, ((u + 1) & 1) * 3 + t);
@@ -401,7 +426,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       int s = 0;
       for (int f = 0; f < nfills; ++f) {
         for (int t = 0; t < spf; ++t, ++s) {
-          if (a.diag != 2) {
+          if (!GGW_DIAG(2)) {
             if (t == 0 && f + 1 < nfills) WIN_FILL(f + 1);
             if (s + RING - 1 < nstages) WIN_WLOAD(s + RING - 1);
           }
@@ -430,6 +455,21 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       akey[slot_][i] = swz<BK>(R);                                           \
     }                                                                        \
   } while (0)
+    // the same in two halves: the rulebook entries of the next stage's tap are requested behind the current stage's
+    // last fragment reads (they land under its last k-step), the table is finished after the last MFMA
+#define ROW_LOAD(tap_, dst_)                                                 \
+  do {                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) dst_[i] = nbr_lds[(tap_) * BM + wm * WTM + i * 32 + lr]; \
+  } while (0)
+#define ROW_FINISH(src_, lo_, slot_)                                         \
+  do {                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                         \
+      const int site = wm * WTM + i * 32 + lr;                               \
+      const int R = src_[i] >= 0 ? (win ? src_[i] - (lo_) : site) : WMAX;    \
+      aoff[slot_][i] = R * ROWB;                                             \
+      akey[slot_][i] = swz<BK>(R);                                           \
+    }                                                                        \
+  } while (0)
 #define DS_READ_FRAG(dst, base, key, ks) \
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((base) + (unsigned)(((2 * (ks)) ^ (key)) << 4)))
     // Hand-ordered k-steps of one (tap, channel chunk) (inline asm; hipcc's own order exposed the LDS latency
@@ -440,7 +480,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     // out before the first MFMA of step ks (128 x 64 tiles on a 90 x 90 map: 19.1 -> 16.1 us, the 16-output
     // heat-map conv 23.5 -> 20.5; on four or more MFMAs per k-step the same order costs 5-8 registers and is
     // 0-5 % slower).
-#define STAGE_MFMA(abase_, wbase_, slot_)                                                                  \
+#define STAGE_MFMA(abase_, wbase_, slot_, pre_)                                                            \
   do {                                                                                                     \
     const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(abase_);      \
     const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(wbase_);      \
@@ -480,6 +520,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
           }                                                                                                \
         }                                                                                                  \
       }                                                                                                    \
+      if (ks == (BK / 16 >= 2 ? BK / 16 - 2 : 0)) {   /* every fragment read of the stage is out */        \
+        pre_;                                                                                              \
+      }                                                                                                    \
     }                                                                                                      \
   } while (0)
     if (unit_mode) {
@@ -490,9 +533,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       for (int u = 0; u < nfills; ++u) {
         GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 0);
         const char* abase = smem + (u & 1) * ABUF;
-        if (a.diag != 1) {
+        if (!GGW_DIAG(1)) {
 #pragma unroll
-          for (int t = 0; t < 3; ++t) STAGE_MFMA(abase, wsm + ((u & 1) * 3 + t) * WBUF, t);
+          for (int t = 0; t < 3; ++t) STAGE_MFMA(abase, wsm + ((u & 1) * 3 + t) * WBUF, t, (void)0);
         }
         if (u + 1 < nfills) {
 #pragma unroll
@@ -508,17 +551,27 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 3);
       __builtin_amdgcn_s_barrier();
       GGW_STAMP(wave == 0, 1);
+      int st = 0, skc = 0, sg = 0, par = 0, ring = 0;   // this stage's coordinates, window buffer, weight slot
       for (int s = 0; s < nstages; ++s) {
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
         GGW_WSTAMP(s, 2);
 #ifdef GGW_KSTAMPS
         kstamp_stage = s;
 #endif
-        const char* abase = smem + ((win ? s / TPG : s) & 1) * ABUF;
-        if (a.diag != 1) {
-          STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
+        STAGE_NEXT(t1, kc1, g1, st, skc, sg);
+        const bool more = s + 1 < nstages;
+        const char* abase = smem + par * ABUF;
+        int nsrc[TM];
+        const int ntap = more ? TPG * g1 + t1 : 0;   // (behind the last stage: any valid entry, unused -- no branch in the loop)
+        if (GGW_DIAG(1)) {
+          ROW_LOAD(ntap, nsrc);
+        } else {
+          STAGE_MFMA(abase, wsm + ring * WBUF, 0, ROW_LOAD(ntap, nsrc));
         }
-        if (s + 1 < nstages) ROW_TABLE(s + 1, 0);   // static rulebook tile: next stage's rows before the barrier
+        ROW_FINISH(nsrc, UNIT_SEL(g1, lo0, lo1, lo2), 0);   // next stage's rows before the barrier
+        if (!win || t1 == 0) par ^= 1;
+        ring = ring + 1 == RING ? 0 : ring + 1;
+        st = t1, skc = kc1, sg = g1;
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         GGW_WSTAMP(s, 0);
@@ -539,18 +592,40 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     GGW_STAMP(wave == 0, 1);
+    int st = 0, skc = 0, sg = 0, par = 0, ring = 0, f = 0;   // this stage's coordinates, window buffer, weight slot, fill
     for (int s = 0; s < nstages; ++s) {
-      const int f = win ? s / TPG : s;
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
-      const bool fill_now = (!win || s - f * TPG == 0) && f + 1 < nfills;
+      STAGE_NEXT(t1, kc1, g1, st, skc, sg);
+      const bool more = s + 1 < nstages;
+      const bool fill_now = (!win || st == 0) && f + 1 < nfills;
+      const int ring1 = ring + 1 == RING ? 0 : ring + 1;
       if (stager) {
-        if (s + 1 < nstages) WIN_WLOAD(s + 1);
-        if (fill_now) WIN_FILL(f + 1);   // issued last: a window (needed three stages on) stays in flight over this barrier
+        if (more) WIN_WLOAD_AT(ring1, g1, kc1, t1);
+        if (fill_now) {   // issued last: a window (needed three stages on) stays in flight over this barrier
+          if (win) {      // the chunk after this one
+            int kcf = skc + 1, gf = sg;
+            if (kcf == kchunks) {
+              kcf = 0;
+              ++gf;
+            }
+            WIN_FILL_AT(par ^ 1, gf, kcf, 0);
+          } else {        // gather mode: the next stage's tap
+            WIN_FILL_AT(par ^ 1, g1, kc1, t1);
+          }
+        }
       }
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // DMA issued
-      const char* abase = smem + (f & 1) * ABUF;
-      STAGE_MFMA(abase, wsm + (s % RING) * WBUF, 0);
-      if (s + 1 < nstages) ROW_TABLE(s + 1, 0);
+      const char* abase = smem + par * ABUF;
+      int nsrc[TM];
+      const int ntap = more ? TPG * g1 + t1 : 0;   // (behind the last stage: any valid entry, unused -- no branch in the loop)
+      STAGE_MFMA(abase, wsm + ring * WBUF, 0, ROW_LOAD(ntap, nsrc));
+      ROW_FINISH(nsrc, UNIT_SEL(g1, lo0, lo1, lo2), 0);
+      if (!win || t1 == 0) {
+        par ^= 1;
+        ++f;
+      }
+      ring = ring1;
+      st = t1, skc = kc1, sg = g1;
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
       if (fill_now && win) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
