@@ -381,6 +381,16 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       ++g1_;                                          \
     }                                                 \
   }
+#define STAGE_ADV(t_, kc_, g_)      \
+  do {                              \
+    if (++(t_) == TPG) {            \
+      (t_) = 0;                     \
+      if (++(kc_) == kchunks) {     \
+        (kc_) = 0;                  \
+        ++(g_);                     \
+      }                             \
+    }                               \
+  } while (0)
 #define WIN_WLOAD_AT(slot_, g_, kc_, t_) \
   win_wload<BK, BN, NLD, NWP, NPA>(wsm + (slot_) * WBUF, rs_wt, lw, TPG * (g_) + (t_), (kc_), a.cout_total, a.cin, LL)
 #define WIN_FILL_AT(par_, g_, kc_, t_)                                                                       \
@@ -409,14 +419,21 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       WIN_WLOAD_SLOT(2, 2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      int ukc = 0, ug = 0;   // this unit's channel chunk and kernel row
       for (int u = 0; u < nfills; ++u) {
+        int kc1 = ukc + 1, g1 = ug;
+        if (kc1 == kchunks) {
+          kc1 = 0;
+          ++g1;
+        }
         if (u + 1 < nfills && !GGW_DIAG(2)) {
-          WIN_FILL(u + 1);
+          WIN_FILL_AT((u + 1) & 1, g1, kc1, 0);
 #pragma unroll
-          for (int t = 0; t < 3; ++t) WIN_WLOAD_SLOT(3 * (u + 1) + t, ((u + 1) & 1) * 3 + t);
+          for (int t = 0; t < 3; ++t) WIN_WLOAD_AT(((u + 1) & 1) * 3 + t, g1, kc1, t);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        ukc = kc1, ug = g1;
       }
     } else {
       // ---- loader waves.  Per stage: the next fill (at the first stage of the current one) and the weights
@@ -426,7 +443,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       int s = 0;
       for (int f = 0; f < nfills; ++f) {
         for (int t = 0; t < spf; ++t, ++s) {
-          if (!GGW_DIAG(2)) {
+          if (!GGW_DIAG(2)) {   // (stage indices divided out here: measured no slower than advancing them, the loaders are not on the critical path)
             if (t == 0 && f + 1 < nfills) WIN_FILL(f + 1);
             if (s + RING - 1 < nstages) WIN_WLOAD(s + RING - 1);
           }
@@ -530,17 +547,28 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       for (int t = 0; t < 3; ++t) ROW_TABLE(t, t);
       __builtin_amdgcn_s_barrier();
       GGW_STAMP(wave == 0, 1);
+      int ukc = 0, ug = 0;   // this unit's channel chunk and kernel row
       for (int u = 0; u < nfills; ++u) {
         GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 0);
         const char* abase = smem + (u & 1) * ABUF;
-        if (!GGW_DIAG(1)) {
-#pragma unroll
-          for (int t = 0; t < 3; ++t) STAGE_MFMA(abase, wsm + ((u & 1) * 3 + t) * WBUF, t, (void)0);
+        int kc1 = ukc + 1, g1 = ug;
+        if (kc1 == kchunks) {
+          kc1 = 0;
+          ++g1;
         }
-        if (u + 1 < nfills) {
-#pragma unroll
-          for (int t = 0; t < 3; ++t) ROW_TABLE(3 * (u + 1) + t, t);   // static rulebook tile: before the barrier
+        const int gn = u + 1 < nfills ? g1 : 0;   // (behind the last unit: any valid entries, unused)
+        int nsrc[3][TM];
+#define ROW_LOAD3 ROW_LOAD(TPG * gn + 0, nsrc[0]); ROW_LOAD(TPG * gn + 1, nsrc[1]); ROW_LOAD(TPG * gn + 2, nsrc[2])
+        if (GGW_DIAG(1)) {
+          ROW_LOAD3;
+        } else {
+          STAGE_MFMA(abase, wsm + ((u & 1) * 3 + 0) * WBUF, 0, (void)0);
+          STAGE_MFMA(abase, wsm + ((u & 1) * 3 + 1) * WBUF, 1, (void)0);
+          STAGE_MFMA(abase, wsm + ((u & 1) * 3 + 2) * WBUF, 2, ROW_LOAD3);   // next unit's rulebook entries under the last k-step
         }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ROW_FINISH(nsrc[t], UNIT_SEL(gn, lo0, lo1, lo2), t);   // before the barrier
+        ukc = kc1, ug = g1;
         GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
