@@ -575,10 +575,41 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         GGW_STAMP(wave == 0 && u < GGW_STAMP_STAGES, 4 + u * 4 + 2);
       }
     } else {
+      // ---- per-tap stages as one stream of k-steps.  The stage barrier sits at the top of a stage's LAST k-step:
+      // by then every fragment read of the stage has landed (its buffers are free for the loaders), and what the
+      // barrier publishes -- the next stage's window and weights -- is first needed by the reads that go out behind
+      // that k-step's MFMAs.  So the first fragments of stage s+1 land under the last MFMAs of stage s instead of
+      // behind a barrier all sixteen waves leave at once (stamps of the barrier-at-the-end loop: ~300 of a stage's
+      // 1 800 ticks from the barrier to the first MFMA).  The next stage's row table and fragment addresses are made
+      // after the stage's last own read has gone out, in the registers of its own.
+      constexpr int NKS = BK / 16;
+      static_assert(NKS >= 2, "two k-steps per stage at least");
       ROW_TABLE(0, 0);
       GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 3);
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();          // stage 0's window and weights have landed
       GGW_STAMP(wave == 0, 1);
+      unsigned ra[TM], rw[TN];
+      int ka[TM], kw[TN];
+      bf16x8 fa[2][TM], fw[2][TN];
+#define FRAG_SETUP(abase_, wbase_)                                                                         \
+  do {                                                                                                     \
+    const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(abase_);      \
+    const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(wbase_);      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
+      ra[i] = a_lds + (unsigned)aoff[0][i];                                                                \
+      ka[i] = akey[0][i] ^ lh;                                                                             \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                       \
+      const int row_ = wn * WTN + j * 32 + lr;                                                             \
+      rw[j] = w_lds + (unsigned)(row_ * ROWB);                                                             \
+      kw[j] = swz<BK>(row_) ^ lh;                                                                          \
+    }                                                                                                      \
+  } while (0)
+      FRAG_SETUP(smem, wsm);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) DS_READ_FRAG(fa[0][i], ra[i], ka[i], 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) DS_READ_FRAG(fw[0][j], rw[j], kw[j], 0);
       int st = 0, skc = 0, sg = 0, par = 0, ring = 0;   // this stage's coordinates, window buffer, weight slot
       for (int s = 0; s < nstages; ++s) {
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
@@ -587,26 +618,52 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         kstamp_stage = s;
 #endif
         STAGE_NEXT(t1, kc1, g1, st, skc, sg);
-        const bool more = s + 1 < nstages;
-        const char* abase = smem + par * ABUF;
+        const int ntap = s + 1 < nstages ? TPG * g1 + t1 : 0;   // (behind the last stage: any valid entry, unused -- no branch in the loop)
+        const int par1 = (!win || t1 == 0) ? par ^ 1 : par;
+        const int ring1 = ring + 1 == RING ? 0 : ring + 1;
         int nsrc[TM];
-        const int ntap = more ? TPG * g1 + t1 : 0;   // (behind the last stage: any valid entry, unused -- no branch in the loop)
-        if (GGW_DIAG(1)) {
-          ROW_LOAD(ntap, nsrc);
-        } else {
-          STAGE_MFMA(abase, wsm + ring * WBUF, 0, ROW_LOAD(ntap, nsrc));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (ks == NKS - 1) {
+            GGW_WSTAMP(s, 0);
+            __builtin_amdgcn_s_barrier();
+            GGW_WSTAMP(s, 1);
+          }
+          GGW_KSTAMP(ks);
+          // reads of the next k-step: ks + 1 of this stage, or k-step 0 of the next (ra / rw then hold its addresses)
+          const int kn = ks + 1 < NKS ? ks + 1 : 0;
+          int nxt = 0;
+          if (TM * TN <= 2) {
+#pragma unroll
+            for (; nxt < TM + TN; ++nxt) {
+              if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], kn);
+              else DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], kn);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fw[ks & 1][j]), "v"(fa[ks & 1][i]));
+#pragma unroll
+              for (int r = 0; r < 2; ++r, ++nxt) {
+                if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], kn);
+                else if (nxt < TM + TN) DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], kn);
+              }
+            }
+          if (ks == (NKS >= 3 ? NKS - 3 : 0)) ROW_LOAD(ntap, nsrc);
+          if (ks == NKS - 2) {   // the stage's own reads are all out: its address registers take the next stage's
+            ROW_FINISH(nsrc, UNIT_SEL(g1, lo0, lo1, lo2), 0);
+            FRAG_SETUP(smem + par1 * ABUF, wsm + ring1 * WBUF);
+          }
         }
-        ROW_FINISH(nsrc, UNIT_SEL(g1, lo0, lo1, lo2), 0);   // next stage's rows before the barrier
-        if (!win || t1 == 0) par ^= 1;
-        ring = ring + 1 == RING ? 0 : ring + 1;
+        par = par1, ring = ring1;
         st = t1, skc = kc1, sg = g1;
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        GGW_WSTAMP(s, 0);
-        __builtin_amdgcn_s_barrier();
-        GGW_WSTAMP(s, 1);
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued behind the last k-step (unused) have landed
     }
   }
   } else {
