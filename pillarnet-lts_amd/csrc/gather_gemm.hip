@@ -27,6 +27,11 @@
 // (read back with pn_gg_debug_stamps; a tuning aid, not part of the public header)
 static constexpr int GG_STAMP_WG = 4, GG_STAMP_STAGES = 40, GG_STAMP_PER = 6;
 __device__ unsigned long long gg_stamps[GG_STAMP_WG * GG_STAMP_STAGES * GG_STAMP_PER];
+// Probe builds only (-DGGW_STAMPS, scripts/build_probe_lib.sh): in the shipped kernels the
+// stamps and the probes that drop the MFMAs (diag 1) or the staging (diag 2) are compiled out -- a scalar branch per
+// hook costs the stage loop ~20 cycles.
+#ifdef GGW_STAMPS
+#define GG_DIAG(x) (a.diag == (x))
 #define GG_STAMP(slot)                                                                                  \
   do {                                                                                                  \
     if (a.diag == 3 && wave == 0 && blockIdx.x < GG_STAMP_WG && s < GG_STAMP_STAGES && blockIdx.y == 0) { \
@@ -34,6 +39,10 @@ __device__ unsigned long long gg_stamps[GG_STAMP_WG * GG_STAMP_STAGES * GG_STAMP
       if (lane == 0) gg_stamps[(blockIdx.x * GG_STAMP_STAGES + s) * GG_STAMP_PER + (slot)] = t_;         \
     }                                                                                                   \
   } while (0)
+#else
+#define GG_DIAG(x) false
+#define GG_STAMP(slot) do {} while (0)
+#endif
 
 extern "C" int pn_gg_debug_stamps(unsigned long long* host_out, int n) {
   const int total = GG_STAMP_WG * GG_STAMP_STAGES * GG_STAMP_PER;
@@ -216,14 +225,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gather_gemm_kernel(GGArgs a) {
   for (int s = 0; s < stages; ++s) {
     GG_STAMP(0);
     if constexpr (DMA) {
-      if (s + NBUF - 1 < stages && a.diag != 2) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+      if (s + NBUF - 1 < stages && !GG_DIAG(2)) issue_dma(s + NBUF - 1, (s + NBUF - 1) % NBUF);
     } else {
       if (s + 1 < stages) issue(s + 1);
     }
     GG_STAMP(1);
     const char* abase = smem + (s % NBUF) * BUF_BYTES;
     const char* wbase = abase + BM * ROWB;
-    if (a.diag != 1)
+    if (!GG_DIAG(1))
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fa[TM], fw[TN];

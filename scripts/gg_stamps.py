@@ -1,4 +1,5 @@
-"""Reads the s_memtime stamps of the per-tap gather-GEMM (PN_GG_DIAG=3, PN_GG_NO_WIN=1) on one layer shape."""
+"""Reads the s_memtime stamps of the per-tap gather-GEMM (PN_GG_DIAG=3, PN_GG_NO_WIN=1) on one layer shape.
+Needs the probe build of the library (scripts/build_probe_lib.sh, PN_LIB_PATH=.../scripts/ab/stamps.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PN_GG_DIAG"] = "3"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the probe build of the library: scripts/build_probe_lib.sh, then PN_LIB_PATH=$GRAFT_REPO_ROOT/scripts/ab/stamps.so
+# (the shipped kernels carry no probe code)
 # window-kernel probes on the dense 180^2 256->256 layer: config x diag mode
 for cfg in "" A L; do
   for diag in 0 1 2; do
