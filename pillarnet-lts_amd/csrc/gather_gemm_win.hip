@@ -712,9 +712,12 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
       ring = ring1;
       st = t1, skc = kc1, sg = g1;
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
+      GGW_WSTAMP(s, 2);   // (fused loop: slot 2 = MFMAs issued, slot 0 = own DMA landed, slot 1 = barrier passed)
       if (fill_now && win) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      GGW_WSTAMP(s, 0);
       __builtin_amdgcn_s_barrier();
+      GGW_WSTAMP(s, 1);
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
     }
   }
