@@ -50,21 +50,27 @@ __device__ __forceinline__ void win_fill(char* base, __amdgpu_buffer_rsrc_t rs_i
   constexpr int CH = BK / 8, ROWB = BK * 2, RPP = 1024 / ROWB;
   if (win) {
     const unsigned soff = (unsigned)lo * in_row_bytes + (unsigned)(kc * ROWB);   // scalar
+    if constexpr (ALL) {
+      // every piece is issued, without a branch (a scalar branch per piece costs the issuing wave ~20 cycles, and
+      // in a fill stage the staging waves are the ones the barrier waits for): a piece past the run reads out of
+      // range -- zeros -- onto the (always zero) rows behind the window
 #pragma unroll
-    for (int j = 0; j < NPA; ++j) {
-      const int piece = wave + j * NW;
-      if (piece * RPP >= cnt) {
-        if constexpr (ALL) {   // out-of-range source: zeros land on the (always zero) rows behind the window
-          auto lds0 = (__attribute__((address_space(3))) void*)(base + WMAX * ROWB);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds0, 16, GG_OOB, 0, 0, 0);
-          continue;
-        } else {
-          break;
-        }
+      for (int j = 0; j < NPA; ++j) {
+        const int piece = wave + j * NW;
+        const bool in_run = piece * RPP < cnt;
+        const unsigned off = L.arow[j] < cnt ? L.a[j] : GG_OOB;   // (arow >= piece * RPP: out of range whenever the piece is)
+        auto lds = (__attribute__((address_space(3))) void*)(base + (in_run ? piece * 1024 : WMAX * ROWB));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, soff, 0, 0);
       }
-      const unsigned off = L.arow[j] < cnt ? L.a[j] : GG_OOB;
-      auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, soff, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPA; ++j) {
+        const int piece = wave + j * NW;
+        if (piece * RPP >= cnt) break;
+        const unsigned off = L.arow[j] < cnt ? L.a[j] : GG_OOB;
+        auto lds = (__attribute__((address_space(3))) void*)(base + piece * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, lds, 16, off, soff, 0, 0);
+      }
     }
   } else {
 #pragma unroll
