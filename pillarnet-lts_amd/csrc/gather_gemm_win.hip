@@ -683,9 +683,20 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     GGW_STAMP(wave == 0, 1);
+    constexpr int FNKS = BK / 16;
+    static_assert(FNKS >= 2, "two k-steps per stage at least");
+    unsigned ra[TM], rw[TN];
+    int ka[TM], kw[TN];
+    bf16x8 fa[2][TM], fw[2][TN];
+    FRAG_SETUP(smem, wsm);
     int st = 0, skc = 0, sg = 0, par = 0, ring = 0, f = 0;   // this stage's coordinates, window buffer, weight slot, fill
     for (int s = 0; s < nstages; ++s) {
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 0);
+      // first fragments of the stage: right behind the barrier, ahead of the DMA burst
+#pragma unroll
+      for (int i = 0; i < TM; ++i) DS_READ_FRAG(fa[0][i], ra[i], ka[i], 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) DS_READ_FRAG(fw[0][j], rw[j], kw[j], 0);
       STAGE_NEXT(t1, kc1, g1, st, skc, sg);
       const bool more = s + 1 < nstages;
       const bool fill_now = (!win || st == 0) && f + 1 < nfills;
@@ -706,15 +717,36 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         }
       }
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 3);   // DMA issued
-      const char* abase = smem + par * ABUF;
       int nsrc[TM];
       const int ntap = more ? TPG * g1 + t1 : 0;   // (behind the last stage: any valid entry, unused -- no branch in the loop)
-      STAGE_MFMA(abase, wsm + ring * WBUF, 0, ROW_LOAD(ntap, nsrc));
-      ROW_FINISH(nsrc, UNIT_SEL(g1, lo0, lo1, lo2), 0);
-      if (!win || t1 == 0) {
-        par ^= 1;
-        ++f;
+      const int par1 = (!win || t1 == 0) ? par ^ 1 : par;
+      // the stage's k-steps; its fragment addresses were made during the previous stage, so the first reads went out
+      // right behind the barrier (above), and the next stage's are made once its own last read is out
+#pragma unroll
+      for (int ks = 0; ks < FNKS; ++ks) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int nxt = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fw[ks & 1][j]), "v"(fa[ks & 1][i]));
+            if (ks + 1 < FNKS) {
+#pragma unroll
+              for (int r = 0; r < 2; ++r, ++nxt) {
+                if (nxt < TM) DS_READ_FRAG(fa[(ks + 1) & 1][nxt], ra[nxt], ka[nxt], ks + 1);
+                else if (nxt < TM + TN) DS_READ_FRAG(fw[(ks + 1) & 1][nxt - TM], rw[nxt - TM], kw[nxt - TM], ks + 1);
+              }
+            }
+          }
+        if (ks == (FNKS >= 3 ? FNKS - 3 : 0)) ROW_LOAD(ntap, nsrc);
+        if (ks == FNKS - 2) {
+          ROW_FINISH(nsrc, UNIT_SEL(g1, lo0, lo1, lo2), 0);
+          FRAG_SETUP(smem + par1 * ABUF, wsm + ring1 * WBUF);
+        }
       }
+      if (!win || t1 == 0) ++f;
+      par = par1;
       ring = ring1;
       st = t1, skc = kc1, sg = g1;
       GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
