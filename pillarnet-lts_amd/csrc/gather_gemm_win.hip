@@ -787,8 +787,24 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
   }
   const bool wide = CPL == 8 && n0 + cl + 8 <= a.cout_total && (a.out_ld & 7) == 0 && (a.res_ld & 7) == 0 &&
                     ((uintptr_t)a.out & 15) == 0 && ((uintptr_t)a.residual & 15) == 0;
+  constexpr int NIT = (PR + NW * RPI - 1) / (NW * RPI);   // output rows per lane and pass
 #pragma unroll
   for (int ep = 0; ep < EP; ++ep) {
+    // the residual rows of the pass are requested before the tile is parked: their round trip runs under the park and
+    // its barrier instead of once per output row behind them
+    bf16x8 rpre[NIT];
+    const bool pre = CPL == 8 && wide && a.residual != nullptr;   // (per lane: `wide` depends on the lane's channels)
+    if constexpr (CPL == 8) {
+      if (pre) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int rp = wave * RPI + it * NW * RPI + sub, m = m0 + rp + ep * PR;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) rpre[it][r] = (__bf16)0.f;
+          if (rp < PR && m < M) rpre[it] = *reinterpret_cast<const bf16x8*>(a.residual + (size_t)m * a.res_ld + n0 + cl);
+        }
+      }
+    }
     if (!loader) {
       const int wm = wave / NWN, wn = wave % NWN;
       if ((wm * WTM) / PR == ep) {                   // wave-uniform
@@ -812,8 +828,9 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
     if (ep == 0) GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 4);
     __syncthreads();
     if (ep == 0) GGW_STAMP(wave == 0, 4 + GGW_STAMP_STAGES * 4 + 5);
-#pragma unroll 8
-    for (int r0 = wave * RPI; r0 < PR; r0 += NW * RPI) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r0 = wave * RPI + it * NW * RPI;
       const int rp = r0 + sub, rl = rp + ep * PR, m = m0 + rl;
       if (!(rp < PR && m < M)) continue;
       const size_t orow = a.out_rows ? (size_t)a.out_rows[m] : (size_t)m;
@@ -827,7 +844,7 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
             if (h == 1) break;
             v2 = *reinterpret_cast<const f32x4*>(et + rp * EROW + c * 4 + 16) * sc[CPL / 4 - 1] + sh[CPL / 4 - 1];
             if (a.residual) {
-              const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.residual + (size_t)m * a.res_ld + n0 + c);
+              const bf16x8 rv = rpre[it];
 #pragma unroll
               for (int r = 0; r < 4; ++r) { v[r] += (float)rv[r]; v2[r] += (float)rv[4 + r]; }
             }
