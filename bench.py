@@ -141,6 +141,21 @@ def cpu_baseline(model, cfg, full_1t=False):
                "dynamic_pillarize_pfn_scatter_s": round(t_dyn, 4), "pillars": int(r["indices"].shape[0]),
                "note": "points_to_voxel restatement (voxel 0.075x0.075x0.2, 10 points/voxel, 120000 voxels) and "
                        "the dynamic reader, 300000 points, 1 thread"}}
+    # configs[0]'s own workload: ONE sweep of 30 000 points through the CPU voxelizer and the CPU forward (the GPU side
+    # of that frame is pinned by tests/test_fullsize_gpu.py's nusc1 cases, not timed here)
+    frame1 = synth.nusc_frame(1, 30000, seed=0)
+    torch.set_num_threads(1)
+    t0 = time.time()
+    vox1, _, _ = voxelize.points_to_voxel(frame1, [0.075, 0.075, 0.2], rd.pc_range, 10, True, 120000)
+    t_hard1 = time.time() - t0
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    d1 = do.pillarnet_forward(sd, [frame1], cfg.model, test_cfg)
+    dt0 = time.time() - t0
+    out["configs0"] = {"value": round(1.0 / (dt0 + t_hard1), 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                       "sample": f"1 frame of configs[0] (1 sweep x 30000 points, fp32, {len(d1[0]['scores'])} detections): hard "
+                                 f"voxelizer {t_hard1 * 1e3:.1f} ms on 1 thread ({int(vox1.shape[0])} voxels) + "
+                                 f"oracle/detector_oracle.py forward {dt0:.1f} s on {cores} threads"}
     if full_1t:
         dt1, _ = whole(1)
         out["one_thread"] = {"value": round(1.0 / dt1, 5), "unit": "frames/s", "seconds": round(dt1, 1)}
@@ -282,34 +297,95 @@ def run_infer(args):
         elapsed_h2d = _max_over_ranks(dist, time.perf_counter() - t0, dev)
 
         cin, cout = (int(v) for v in args.probe.split("x"))
-        sparse_conv.EVENT_PROBE.update(shape=(cin, cout), events=[])
-        for i in range(min(args.steps, 8)):
-            model(examples[i % len(examples)], return_loss=False)
-        torch.cuda.synchronize()
-        ev = sparse_conv.EVENT_PROBE["events"]
-        roof = None
-        if ev:
-            # algorithmic flops = 2*Cin*Cout * (active (site, tap) pairs), counted on the live rulebook
+        peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+
+        def probe_conv(policy, busy_lane):
+            """HIP-event pairs on the launch stream around every sparse `cin -> cout` launch of eager frames recorded
+            under tile policy `policy`; with `busy_lane` the other lane's frame graph is replayed beside them on its own
+            stream, as in the timed loop.  -> (average ms, launches, active (site, tap) pairs, rows, row capacity the
+            launch is sized by)."""
+            from pillarnet_lts_amd import _lib
+            old_policy = _lib.lib().pn_gg_set_tile_policy(policy)
+            sparse_conv.EVENT_PROBE.update(shape=(cin, cout), events=[])
+            try:
+                for rep in range(4):
+                    if busy_lane is not None:
+                        fr = next(iter(busy_lane.frames.values()))
+                        with torch.cuda.stream(busy_lane.stream):
+                            for _ in range(6):               # ~6 ms of the other frame's kernels queued ahead
+                                fr.graph.replay()
+                    for i in range(2):
+                        model(examples[(2 * rep + i) % len(examples)], return_loss=False)
+                    torch.cuda.synchronize()
+            finally:
+                _lib.lib().pn_gg_set_tile_policy(old_policy)
+            ev = sparse_conv.EVENT_PROBE["events"]
+            if not ev:
+                return None
             avg_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
             nbr, rows = sparse_conv.EVENT_PROBE["rules"], int(sparse_conv.EVENT_PROBE["rows"].item())
             pairs = int((nbr[:, :rows] >= 0).sum().item())
-            flops = 2.0 * cin * cout * pairs
-            peak = 2500.0 if dtype == torch.bfloat16 else 157.3
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same shape)
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            sparse_conv.EVENT_PROBE.update(shape=None, events=[], rules=None, rows=None)
+            return avg_ms, len(ev), pairs, rows, int(nbr.shape[1])
+
+        def pmc_traffic(key, *names):
+            # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same layer shape)
+            for name in names:
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
-                        pmc = json.load(f)
-                    traffic = (pmc.get(f"spconv_{cin}x{cout}_window") or pmc.get(f"spconv_{cin}x{cout}", {})).get("hbm_bytes_per_launch")
-                    break
+                        hit = json.load(f).get(key)
                 except OSError:
                     continue
-            roof = {"bound": "mfma", "kernel": f"gg_win_kernel<..,{args.dtype}> (window-staged gather-GEMM, sparse SubM {cin}->{cout})",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2),
-                    "active_pairs": pairs, "rows": rows}
-        sparse_conv.EVENT_PROBE.update(shape=None, events=[], rules=None, rows=None)
+                if hit:
+                    return hit.get("hbm_bytes_per_launch")
+            return None
+
+        # (1) the kernel the TIMED loop runs for this layer: graphs are recorded under the shared-CU tile policy, where a
+        # 256-wide stride-1 layer is 256 x 256 tiles on fused waves -- half as many workgroups as CUs, the other frame's
+        # kernels beside it.  Measured the same way: policy 1, the other lane replaying its graph.
+        roof = roof_one = None
+        shared = (not args.no_graph) and getattr(runner, "shared_cu_tiles", False)
+        if shared and len(runner.lanes) > 1:
+            got = probe_conv(1, runner.lanes[1])
+            if got:
+                avg_ms, n, pairs, rows, cap = got
+                ach = 2.0 * cin * cout * pairs / (avg_ms * 1e-3) / 1e12
+                tiles = -(-cap // 256) * -(-cout // 256)
+                cus = min(256, tiles)
+                roof = {"bound": "mfma",
+                        "kernel": f"gg_win_kernel<256,256,4,2,0,64,264,{args.dtype},...,FUSED> (window-staged gather-GEMM on 256x256 "
+                                  f"tiles, sparse SubM {cin}->{cout}; the kernel the timed graphs run for the 256-wide layers)",
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": pmc_traffic(f"spconv_{cin}x{cout}_fused", "r03_pmc_traffic.json"), "launches": n, "avg_us": round(avg_ms * 1e3, 2),
+                        "active_pairs": pairs, "rows": rows, "workgroups": tiles, "cus_used": cus,
+                        "frac_of_occupied_cus": round(ach / (peak * cus / 256.0), 4),
+                        "measured": "HIP events around the launches of eager frames under the graphs' tile policy while "
+                                    "the other lane replays its frame graph"}
+        # (2) the same layer when a launch owns the chip (one frame at a time): 128 x 256 tiles, one per CU
+        got = probe_conv(0, None)
+        if got:
+            avg_ms, n, pairs, rows, cap = got
+            ach = 2.0 * cin * cout * pairs / (avg_ms * 1e-3) / 1e12
+            roof_one = {"bound": "mfma", "kernel": f"gg_win_kernel<128,256,2,4,8,...,{args.dtype}> (one launch owns the chip: "
+                                                   f"one-frame-at-a-time loop), sparse SubM {cin}->{cout}",
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": pmc_traffic(f"spconv_{cin}x{cout}_window", "r03_pmc_traffic.json", "r02_pmc_traffic.json"), "launches": n,
+                        "avg_us": round(avg_ms * 1e3, 2), "active_pairs": pairs, "rows": rows}
+        if roof is None:
+            roof = roof_one
+
+        # (3) the frame's matrix work, counted on the live rulebooks of one eager frame: what this path issues (ranked
+        # regression heads: towers only at the selected cells), and the share of the bf16 MFMA peak the timed loop reaches
+        from pillarnet_lts_amd import _lib
+        _lib.FLOP_LOG = []
+        model(examples[0], return_loss=False)
+        torch.cuda.synchronize()
+        by_tag = {}
+        for tag, per_pair, pairs_ in _lib.FLOP_LOG:
+            by_tag[tag] = by_tag.get(tag, 0.0) + per_pair * float(pairs_)
+        _lib.FLOP_LOG = None
+        frame_flops = sum(by_tag.values())
+        top = sorted(by_tag.items(), key=lambda kv: -kv[1])[:8]
 
         # reader (voxelize + PFN + scatter-max) as an HBM stage: HIP events on the launch stream
         reps = 20
@@ -364,6 +440,10 @@ def run_infer(args):
             "value_host_wait_per_frame": round(frames_total / elapsed_sync, 3),
             "value_h2d_inclusive": round(frames_total / elapsed_h2d, 3),
             "roofline": roof,
+            "roofline_one_lane": roof_one,
+            "frame_flops": round(frame_flops),
+            "frame_mfma_frac": round(frame_flops / (elapsed / args.steps * world) / (peak * 1e12), 4),
+            "frame_flops_top_layers_GF": {k: round(v / 1e9, 2) for k, v in top},
             "hbm_stage": hbm_stage,
             "cpu_baseline": cpu,
         }

@@ -164,3 +164,14 @@ def ptr(t):
 def current_stream(device):
     import torch
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# Flop accounting (bench.py's counting pass, off the clock): while this is a list, every matrix launch of the inference
+# path appends (tag, flops per active (row, tap) pair = 2 * cin * cout, pairs) -- pairs an int or a 0-d device tensor
+# counted on the launch's own rulebook, so that what is summed is the work this path issues on this frame.
+FLOP_LOG = None
+
+
+def log_flops(tag, cin, cout, pairs, useful=1.0):
+    if FLOP_LOG is not None:
+        FLOP_LOG.append((tag, 2.0 * cin * cout * useful, pairs))

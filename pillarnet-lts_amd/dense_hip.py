@@ -100,8 +100,12 @@ class Rows:
 
 
 def _launch(x, cin, nbr, ntaps, rows, w, scale, shift, relu, out, out_ld, fp32_out=False, out_rows=None,
-            residual=None, res_ld=0, in_ld=0):
-    """x / out: 2-D views with unit channel stride (their data_ptr carries any channel offset)."""
+            residual=None, res_ld=0, in_ld=0, useful=1.0):
+    """x / out: 2-D views with unit channel stride (their data_ptr carries any channel offset).  `useful`: the share
+    of the weight matrix that is not structural zeros (flop accounting only)."""
+    if _lib.FLOP_LOG is not None:
+        _lib.log_flops(f"dense {cin}->{w.shape[1]} x{ntaps}", cin, w.shape[1],
+                       rows if nbr is None else (nbr[:, :rows] >= 0).sum(), useful)
     rc = _lib.lib().pn_gather_gemm(_lib.ptr(x), cin, in_ld, x.shape[0], _lib.ptr(nbr), 0 if nbr is None else nbr.shape[1], ntaps,
                                    None, rows, _lib.ptr(w), w.shape[1], _lib.ptr(scale), _lib.ptr(shift),
                                    _lib.ptr(residual), res_ld, int(relu), _lib.ptr(out), out_ld, int(fp32_out),
@@ -165,6 +169,7 @@ class UpStep:
         if out is None:
             out = torch.empty((rows_in * 4, self.cout), dtype=torch.bfloat16, device=x.t.device)
         assert out.shape == (rows_in * 4, self.cout) and out.stride(1) == 1
+        _lib.log_flops(f"up2 {self.cin}->{self.cout}", self.cin, self.cout, 4 * rows_in)
         rc = _lib.lib().pn_gather_gemm_grouped(_lib.ptr(x.t), self.cin, x.ld, x.t.shape[0], 0, None, 0, 1, rows_in,
                                                _lib.ptr(self.w), self.cout, 4, _lib.ptr(self.scale),
                                                _lib.ptr(self.shift), int(self.relu), _lib.ptr(out), out.stride(0), 0, 0,
@@ -354,6 +359,7 @@ class HeadPlan:
                 w9 = torch.stack([tc[5] for tc in task_convs]).contiguous()        # [G, 9, npad, kin]
                 one = ones[:G * npad].contiguous()
                 maps = torch.empty((G, rows, npad), dtype=torch.float32, device=dev)
+                _lib.log_flops("head output convs (direct)", kin, npad, G * (nbr[:, :rows] >= 0).sum())
                 rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, _lib.ptr(nbr), nbr.shape[1], 9,
                                               rows, _lib.ptr(w9), npad, G, _lib.ptr(one), _lib.ptr(bias), 0,
                                               _lib.ptr(maps), npad, rows * npad, 1, None, 0, _lib.current_stream(dev))
@@ -366,6 +372,7 @@ class HeadPlan:
                 G = len(task_convs)
                 zdt = torch.float32 if _HEAD_Z_FP32 else torch.bfloat16
                 z = torch.empty((rows, G * 9 * npad), dtype=zdt, device=dev)
+                _lib.log_flops("head per-tap products", kin, 9 * npad, G * rows)
                 rc = L.pn_gather_gemm_grouped(_lib.ptr(tow[:, k0:]), kin, cols, rows, kin, None, 0, 1, rows,
                                               _lib.ptr(wz), 9 * npad, G, _lib.ptr(ones), _lib.ptr(zeros), 0,
                                               _lib.ptr(z), G * 9 * npad, 9 * npad, int(_HEAD_Z_FP32), None, 0,
@@ -484,7 +491,7 @@ class LazyHeadPlan:
             C = G * p["npad_h"]
             z = torch.empty((rows, 9 * C), dtype=torch.float32, device=dev)
             _launch(tow, G * p["tw"], None, 1, rows, p["wz_hm"], p["ones_h"], p["zeros_h"], False, z, 9 * C,
-                    fp32_out=True, in_ld=G * p["tw"])
+                    fp32_out=True, in_ld=G * p["tw"], useful=1.0 / G)
             hm = torch.empty((rows, G, p["npad_h"]), dtype=torch.float32, device=dev)     # task g: hm[:, g, :]
             rc = L.pn_tap_sum(_lib.ptr(z), _lib.PN_DTYPE_F32, 9 * C, 0, _lib.ptr(nbr), nbr.shape[1], rows, C, 1,
                               _lib.ptr(p["b_hm"]), _lib.ptr(hm), C, 0, _lib.current_stream(dev))
@@ -521,6 +528,10 @@ class LazyHeadPlan:
         kin, npad = p["kin_r"], p["npad_r"]
         st = _lib.current_stream(dev)
         tow = torch.empty((Ns, R, kin), dtype=torch.bfloat16, device=dev)
+        if _lib.FLOP_LOG is not None:
+            live = torch.arange(R, device=dev).view(1, 1, R) < row_counts.view(Ns, 1, 1)
+            _lib.log_flops("lazy regression towers", p["cin"], kin, ((nbr_tower.view(Ns, 9, R) >= 0) & live).sum())
+            _lib.log_flops("lazy per-tap products", kin, 9 * npad, row_counts.sum())
         rc = L.pn_gather_gemm_blocks(_lib.ptr(x.t), p["cin"], x.ld, x.t.shape[0], 0, _lib.ptr(nbr_tower), R, 9 * R, 9,
                                      _lib.ptr(row_counts), R, _lib.ptr(w_reg), kin, Ns, _lib.ptr(sc), _lib.ptr(sh), 1,
                                      _lib.ptr(tow), kin, R * kin, 0, st)

@@ -16,7 +16,8 @@ the upstream CenterPoint conventions and is NUMERICALLY UNPINNED:
   * VoxelNet's 3-D sparse backbone (SpMiddleResNetFHD) constructs but raises on forward: 3-D sparse
     convolution is outside this package's 2-D pillar hot path;
   * TwoStageDetector / BEVFeatureExtractor / RoIHead follow det3d/models/detectors/two_stage.py:10-195,
-    second_stage/bird_eye_view.py:10-41 and roi_heads/roi_head.py:14-111 (inference; the training branch raises).
+    second_stage/bird_eye_view.py:10-41 and roi_heads/roi_head.py:14-111 (inference and the training branch:
+    RoI targets and losses are roi_head_template.py's).
 Pipeline step `Voxelization` = the hard voxelizer (det3d/ops/point_cloud/point_cloud_ops.py:112-184), here as a
 host-side C routine in the library (`pn_points_to_voxel`); legacy `voxel_generator` dicts
 (configs/nusc/voxelnet/nusc_centerpoint_pillarnet_h.py:151-158).
@@ -30,6 +31,7 @@ import torch.nn as nn
 from . import builder
 from .bbox_heads import CenterHead, resolve_legacy_geometry  # noqa: F401
 from .detectors import BaseDetector, PillarNet, SingleStageDetector
+from .second_stage import RoIHeadTemplate
 from .registry import (BACKBONES, DETECTORS, HEADS, NECKS, PIPELINES, READERS, ROI_HEAD, SECOND_STAGE)
 
 _log = logging.getLogger("legacy")
@@ -389,14 +391,14 @@ class BEVFeatureStrideNeck(BEVFeatureNeck):
 
 
 @ROI_HEAD.register_module
-class RoIHead(nn.Module):
+class RoIHead(RoIHeadTemplate):
     """det3d/models/roi_heads/roi_head.py:14-111: shared Conv1d(k1)+BN+ReLU stack, then class and box-residual
-    branches (same parameter names: shared_fc_layer / cls_layers / reg_layers)."""
+    branches (same parameter names: shared_fc_layer / cls_layers / reg_layers); targets and losses are the
+    template's (roi_head_template.py)."""
 
     def __init__(self, input_channels, model_cfg, num_class=1, code_size=7, add_box_param=False, test_cfg=None):
-        super().__init__()
-        self.model_cfg, self.test_cfg, self.code_size, self.add_box_param = model_cfg, test_cfg, code_size, add_box_param
-        self.num_class = num_class
+        super().__init__(num_class=num_class, model_cfg=model_cfg)
+        self.test_cfg, self.code_size, self.add_box_param = test_cfg, code_size, add_box_param
         pre, layers = input_channels, []
         shared = list(model_cfg["SHARED_FC"])
         for k, c in enumerate(shared):
@@ -405,31 +407,24 @@ class RoIHead(nn.Module):
             if k != len(shared) - 1 and model_cfg["DP_RATIO"] > 0:
                 layers.append(nn.Dropout(model_cfg["DP_RATIO"]))
         self.shared_fc_layer = nn.Sequential(*layers)
-        self.cls_layers = self._fc(pre, num_class, model_cfg["CLS_FC"])
-        self.reg_layers = self._fc(pre, code_size, model_cfg["REG_FC"])
+        self.cls_layers = self.make_fc_layers(pre, num_class, model_cfg["CLS_FC"])
+        self.reg_layers = self.make_fc_layers(pre, code_size, model_cfg["REG_FC"])
         for m in self.modules():
-            if isinstance(m, nn.Conv1d):
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
                 nn.init.xavier_normal_(m.weight)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
         nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
 
-    def _fc(self, cin, cout, widths):
-        layers, pre = [], cin
-        for k, c in enumerate(widths):
-            layers += [nn.Conv1d(pre, c, kernel_size=1, bias=False), nn.BatchNorm1d(c), nn.ReLU()]
-            pre = c
-            if self.model_cfg["DP_RATIO"] >= 0 and k == 0:
-                layers.append(nn.Dropout(self.model_cfg["DP_RATIO"]))
-        layers.append(nn.Conv1d(pre, cout, kernel_size=1, bias=True))
-        return nn.Sequential(*layers)
-
     def forward(self, batch_dict, training=True):
-        """roi_head.py:70-111, inference branch."""
-        if training:
-            raise NotImplementedError("legacy RoIHead: training targets are built for RoIMIXHead only")
-        from .second_stage import RoIMIXHead
+        """roi_head.py:70-111."""
         batch_dict["batch_size"] = len(batch_dict["rois"])
+        if training:
+            td = batch_dict.get("roi_targets_dict", None)
+            if td is None:
+                td = self.assign_targets(batch_dict)
+                batch_dict["rois"], batch_dict["roi_labels"], batch_dict["roi_scores"] = \
+                    td["rois"], td["roi_labels"], td["roi_scores"]
         if self.add_box_param:
             batch_dict["roi_features"] = torch.cat([batch_dict["roi_features"], batch_dict["rois"],
                                                     batch_dict["roi_scores"].unsqueeze(-1)], dim=-1)
@@ -437,7 +432,11 @@ class RoIHead(nn.Module):
         shared = self.shared_fc_layer(feats)
         rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
         rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
-        cls, boxes = RoIMIXHead.generate_predicted_boxes(self, batch_dict["batch_size"], batch_dict["rois"], rcnn_cls, rcnn_reg)
+        if training:
+            td["rcnn_cls"], td["rcnn_reg"] = rcnn_cls, rcnn_reg
+            self.forward_ret_dict = td
+            return batch_dict
+        cls, boxes = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"], rcnn_cls, rcnn_reg)
         batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"] = cls, boxes
         batch_dict["cls_preds_normalized"] = False
         return batch_dict
@@ -445,8 +444,8 @@ class RoIHead(nn.Module):
 
 @DETECTORS.register_module
 class TwoStageDetector(BaseDetector):
-    """det3d/models/detectors/two_stage.py:10-195, inference path (the legacy first stages it wraps are the
-    adapters above; their numerics are unpinned, see the module docstring)."""
+    """det3d/models/detectors/two_stage.py:10-195 (the legacy first stages it wraps are the adapters above; their
+    numerics are unpinned, see the module docstring)."""
 
     def __init__(self, first_stage_cfg, second_stage_modules, roi_head, point_head=None, num_point=1, freeze=False,
                  use_final_feature=False, NMS_POST_MAXSIZE=None, **kwargs):
@@ -518,24 +517,36 @@ class TwoStageDetector(BaseDetector):
                         "metadata": batch_dict["metadata"][i]})
         return out
 
+    def combine_loss(self, one_stage_loss, roi_loss, tb_dict):
+        """two_stage.py:43-50."""
+        one_stage_loss["loss"][0] = one_stage_loss["loss"][0] + roi_loss
+        for _ in range(len(one_stage_loss["loss"])):
+            one_stage_loss["roi_reg_loss"].append(tb_dict["rcnn_loss_reg"])
+            one_stage_loss["roi_cls_loss"].append(tb_dict["rcnn_loss_cls"])
+        return one_stage_loss
+
     def forward(self, example, return_loss=True, **kwargs):
-        """two_stage.py:152-195, inference (the second-stage training targets of the legacy RoIHead are not built)."""
-        if return_loss:
-            raise NotImplementedError("legacy TwoStageDetector: inference only; PillarRCNN is the live two-stage detector")
+        """two_stage.py:152-195."""
         out = self.single_det.forward_two_stage(example, return_loss, **kwargs)
         if len(out) == 5:
-            first, bev, example["voxel_feature"], final, _ = out
+            first, bev, example["voxel_feature"], final, one_stage_loss = out
         elif len(out) == 3:
-            first, bev, _ = out
+            first, bev, one_stage_loss = out
             final = None
         else:
             raise NotImplementedError
         src = final if self.use_final_feature else bev
         example["bev_feature"] = src.permute(0, 2, 3, 1).contiguous()
         centers = self.get_box_center(first)
+        if self.roi_head.code_size == 7 and return_loss is True:
+            example["gt_boxes_and_cls"] = example["gt_boxes_and_cls"][:, :, [0, 1, 2, 3, 4, 5, 6, -1]]   # drop velocity
         features = [m.forward(example, centers, self.num_point) for m in self.second_stage]
         example = self.reorder_first_stage_pred_and_feature(first, example, features)
-        return self.post_process(self.roi_head(example, training=False))
+        batch_dict = self.roi_head(example, training=return_loss)
+        if return_loss:
+            roi_loss, tb = self.roi_head.get_loss()
+            return self.combine_loss(one_stage_loss, roi_loss, tb)
+        return self.post_process(batch_dict)
 
 
 # ---- pipeline: the hard voxelizer -----------------------------------------------------------------------------

@@ -275,8 +275,14 @@ class BEVStrideFeature(nn.Module):
             c0 += widths[k + 1]
         return dense_hip.run_stack(fusion, dense_hip.Rows(cat, B, H, W))
 
+    def _hip_plan_fits(self):
+        """the gather-GEMM plans hold 1x1 and 2x2 stride-2 transposed convs; coarser up-sampling stays on torch."""
+        convs = [m for m in self.modules() if isinstance(m, (nn.ConvTranspose2d, nn.Conv2d))]
+        return all(m.kernel_size in ((1, 1), (2, 2)) for m in convs if isinstance(m, nn.ConvTranspose2d)) and \
+            all(m.in_channels % 32 == 0 and m.out_channels % 4 == 0 for m in convs)     # the kernels' channel granularity
+
     def fused_map(self, example):
-        if getattr(self, "_dense_hip", False) and example["bev_feature"].dtype == torch.bfloat16:
+        if getattr(self, "_dense_hip", False) and example["bev_feature"].dtype == torch.bfloat16 and self._hip_plan_fits():
             return self.fused_rows_hip(example).nchw()
         ref = next(self.parameters())
         cast = lambda t: t if t.dtype == ref.dtype else t.to(ref.dtype)
@@ -307,6 +313,47 @@ class BEVStrideFeature(nn.Module):
         example["point_features"] = pooled
         example["point_coords"] = pts
         return example
+
+
+@SECOND_STAGE.register_module
+class BEVFeature(BEVStrideFeature):
+    """bev_interpolation.py:17-159: the older fusion module -- the neck map comes from the stride of `conv4`
+    (BEVStrideFeature: of `conv3`), `conv4` itself may be a lateral source, and a source AT the output stride takes a
+    1x1 sparse conv unless the output stride is 8 (bev_interpolation.py:56).  Map fusion, the rotated RoI lattice
+    and the bilinear gather are the parent's (same forward: bev_interpolation.py:125-158 against :270-308)."""
+
+    def __init__(self, feature_sources, pillar_size, pc_range, out_stride=4, grid_size=7, in_channels=256,
+                 share_channels=64, backbone_channels=None, backbone_strides=None):
+        nn.Module.__init__(self)
+        self.pillar_size, self.point_cloud_range, self.grid_size = pillar_size, pc_range, grid_size
+        strides, names, chans = [1, 2, 4, 8], ["conv1", "conv2", "conv3", "conv4"], [32, 64, 128, 256]
+        assert out_stride in strides
+        k = strides.index(out_stride)
+        out_channels = chans[k]
+        assert out_channels <= backbone_channels[names[k]]
+        s = int(backbone_strides["conv4"] / out_stride)
+        self.top_down_conv = nn.Sequential(nn.ConvTranspose2d(in_channels, out_channels, s, stride=s, bias=False),
+                                           build_norm_layer(_BN2, out_channels)[1], nn.ReLU())
+        c_in = out_channels
+        self.lat_conv, self.lat_conv_name, self.lat_tensor_type = nn.ModuleList(), [], []
+        for src in feature_sources:
+            if src not in names:
+                continue
+            s = backbone_strides[src] / out_stride
+            if s > 1 or (out_stride == 8 and s == 1):
+                s = int(s)
+                self.lat_conv.append(nn.Sequential(
+                    nn.ConvTranspose2d(backbone_channels[src], out_channels, s, stride=s, bias=False),
+                    build_norm_layer(_BN2, out_channels)[1], nn.ReLU()))
+                self.lat_tensor_type.append("dense")
+            else:
+                self.lat_conv.append(SparseLateral(backbone_channels[src], out_channels, int(np.round(1 / s))))
+                self.lat_tensor_type.append("sparse")
+            self.lat_conv_name.append(src)
+            c_in += out_channels
+        self.fusion_conv = nn.Sequential(nn.Conv2d(c_in, share_channels, 3, stride=1, padding=1, bias=True),
+                                         build_norm_layer(_BN2, share_channels)[1], nn.ReLU())
+        self.out_stride = out_stride
 
 
 def rotate_points_along_z(points, angle):
@@ -525,43 +572,22 @@ def _fc_stack(cfg_list, cin, cout, dp_ratio, conv=True):
     return nn.Sequential(*layers)
 
 
-@ROI_HEAD.register_module
-class RoIMIXHead(nn.Module):
-    """roi_mix_head.py:17-122 + roi_head_template.py:22-40,189-219 (inference)."""
+class RoIHeadTemplate(nn.Module):
+    """roi_head_template.py:13-219: what every RoI head shares -- the proposal sampler, the RoI-frame target
+    encoding, class / box / IoU losses and the decoding of residuals back into boxes."""
 
-    def __init__(self, in_channels=None, model_cfg=None, num_class=1, code_size=7, add_box_param=False, test_cfg=None,
-                 mixer_type=None, num_patches=49, **kwargs):
+    def __init__(self, num_class, model_cfg):
         super().__init__()
-        if in_channels is None:
-            in_channels = kwargs.pop("input_channels")          # the legacy configs' name for it
-        self.model_cfg, self.test_cfg, self.num_class = model_cfg, test_cfg, num_class
-        self.code_size, self.add_box_param, self.num_patches = code_size, add_box_param, num_patches
-        if mixer_type == "MLPMixer":
-            self.mlp_mixer = MLPMixer(in_channels=in_channels, num_patches=num_patches)
-        elif mixer_type == "ResMLP":
-            self.mlp_mixer = ResMLPLayer(in_channels=in_channels, num_patches=num_patches)
-        else:
-            self.mlp_mixer = nn.Sequential()
-        pre = in_channels * num_patches
-        shared, fcs = [], list(model_cfg["SHARED_FC"])
-        for k, c in enumerate(fcs):
-            shared += [nn.Conv1d(pre, c, kernel_size=1, bias=False), build_norm_layer(_BN1, c)[1], nn.ReLU()]
-            pre = c
-            if k != len(fcs) - 1 and model_cfg["DP_RATIO"] > 0:
-                shared.append(nn.Dropout(model_cfg["DP_RATIO"]))
-        self.shared_fc_layer = nn.Sequential(*shared)
-        self.cls_layers = _fc_stack(list(model_cfg["CLS_FC"]), pre, num_class, model_cfg["DP_RATIO"])
-        self.reg_layers = _fc_stack(list(model_cfg["REG_FC"]), pre, code_size, model_cfg["DP_RATIO"])
+        self.model_cfg, self.num_class = model_cfg, num_class
         self.proposal_target_layer = ProposalTargetLayer(model_cfg["TARGET_CONFIG"]) if "TARGET_CONFIG" in model_cfg else None
         self.use_iou, self.forward_ret_dict = False, None
-        for m in self.modules():
-            if isinstance(m, (nn.Conv2d, nn.Conv1d)):
-                nn.init.xavier_normal_(m.weight)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-        nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
+
+    def make_fc_layers(self, input_channels, output_channels, fc_list):
+        """roi_head_template.py:23-39."""
+        return _fc_stack(list(fc_list), input_channels, output_channels, self.model_cfg["DP_RATIO"])
 
     def generate_predicted_boxes(self, batch_size, rois, cls_preds, box_preds):
+        """roi_head_template.py:189-219."""
         code = box_preds.shape[-1]
         cls = cls_preds.view(batch_size, -1, cls_preds.shape[-1])
         ry, xyz = rois[:, :, 6].reshape(-1), rois[:, :, 0:3].reshape(-1, 3)
@@ -573,7 +599,7 @@ class RoIMIXHead(nn.Module):
         return cls, boxes.view(batch_size, -1, code)
 
     def assign_targets(self, batch_dict):
-        """roi_head_template.py:42-88: sample RoIs, then express each RoI's GT box in the RoI's own frame."""
+        """roi_head_template.py:41-83: sample RoIs, then express each RoI's GT box in the RoI's own frame."""
         B = batch_dict["batch_size"]
         with torch.no_grad():
             td = self.proposal_target_layer(batch_dict)
@@ -594,11 +620,9 @@ class RoIMIXHead(nn.Module):
         td["gt_of_rois"] = gt
         return td
 
-    def get_loss(self, tb_dict=None):
-        """roi_head_template.py:90-187 (BinaryCrossEntropy / CrossEntropy class loss, L1 box loss)."""
-        tb = {} if tb_dict is None else tb_dict
-        ret, lc = self.forward_ret_dict, self.model_cfg["LOSS_CONFIG"]
-        w = lc["LOSS_WEIGHTS"]
+    def get_box_cls_layer_loss(self, ret):
+        """roi_head_template.py:149-168."""
+        lc = self.model_cfg["LOSS_CONFIG"]
         labels = ret["rcnn_cls_labels"].view(-1)
         valid = (labels >= 0).float()
         if lc["CLS_LOSS"] == "BinaryCrossEntropy":
@@ -607,7 +631,12 @@ class RoIMIXHead(nn.Module):
             per = Fn.cross_entropy(ret["rcnn_cls"], labels, reduction="none", ignore_index=-1)
         else:
             raise NotImplementedError(lc["CLS_LOSS"])
-        loss_cls = (per * valid).sum() / torch.clamp(valid.sum(), min=1.0) * w["rcnn_cls_weight"]
+        loss = (per * valid).sum() / torch.clamp(valid.sum(), min=1.0) * lc["LOSS_WEIGHTS"]["rcnn_cls_weight"]
+        return loss, {"rcnn_loss_cls": loss.detach()}
+
+    def get_box_reg_layer_loss(self, ret):
+        """roi_head_template.py:85-115."""
+        lc = self.model_cfg["LOSS_CONFIG"]
         if lc["REG_LOSS"] != "L1":
             raise NotImplementedError(lc["REG_LOSS"])
         code = ret["rcnn_reg"].shape[-1]
@@ -615,13 +644,79 @@ class RoIMIXHead(nn.Module):
         target = ret["gt_of_rois"][..., 0:code].reshape(-1, code)
         n = target.shape[0]
         per = Fn.l1_loss(ret["rcnn_reg"].view(n, -1), target, reduction="none")
-        per = per * per.new_tensor(w["code_weights"])
-        loss_reg = (per.view(n, -1) * fg.unsqueeze(-1).float()).sum() / max(int(fg.long().sum().item()), 1)
-        loss_reg = loss_reg * w["rcnn_reg_weight"]
-        tb.update(rcnn_loss_cls=loss_cls.detach(), rcnn_loss_reg=loss_reg.detach())
-        total = loss_cls + loss_reg
+        per = per * per.new_tensor(lc["LOSS_WEIGHTS"]["code_weights"])
+        loss = (per.view(n, -1) * fg.unsqueeze(-1).float()).sum() / max(int(fg.long().sum().item()), 1)
+        loss = loss * lc["LOSS_WEIGHTS"]["rcnn_reg_weight"]
+        return loss, {"rcnn_loss_reg": loss.detach()}
+
+    def get_box_iou_layer_loss(self, ret):
+        """roi_head_template.py:117-147: the IoU branch regresses 2 * IoU3D(decoded box, GT) - 1 on the foreground
+        RoIs (rotated 3-D IoU on the HIP kernel, det3d/ops/iou3d_nms/iou3d_nms_utils.py:77-111)."""
+        lc = self.model_cfg["LOSS_CONFIG"]
+        if lc["IOU_LOSS"] != "L1":
+            raise NotImplementedError(lc["IOU_LOSS"])
+        fg = ret["reg_valid_mask"].view(-1) > 0
+        n_fg = int(fg.long().sum().item())
+        iou_fn = getattr(self, "aligned_iou_fn", None) or iou3d_nms.boxes_aligned_iou3d_gpu
+        pred = ret["batch_box_preds"].view(-1, 7).detach()[fg]
+        gt = ret["gt_of_rois_src"][..., :7].reshape(-1, 7)[fg]
+        target = 2 * iou_fn(pred, gt) - 1 if n_fg else pred.new_zeros((0, 1))
+        # shapes as in the reference: predictions [n] against targets [n, 1] broadcast to ALL n x n pairs before the
+        # sum (roi_head_template.py:131-139) -- kept, so that losses and gradients equal the reference's
+        est = ret["rcnn_iou"].view(-1)[fg]
+        loss = (est.view(1, -1) - target.view(-1, 1).to(est.dtype)).abs().sum()
+        loss = loss / max(n_fg, 1) * lc["LOSS_WEIGHTS"]["rcnn_iou_weight"]
+        return loss, {"rcnn_loss_iou": loss.detach()}
+
+    def get_loss(self, tb_dict=None):
+        """roi_head_template.py:170-187."""
+        tb = {} if tb_dict is None else tb_dict
+        total, t = self.get_box_cls_layer_loss(self.forward_ret_dict)
+        tb.update(t)
+        reg, t = self.get_box_reg_layer_loss(self.forward_ret_dict)
+        total = total + reg
+        tb.update(t)
+        if self.use_iou:
+            iou, t = self.get_box_iou_layer_loss(self.forward_ret_dict)
+            total = total + iou
+            tb.update(t)
         tb["rcnn_loss"] = total.item()
         return total, tb
+
+
+@ROI_HEAD.register_module
+class RoIMIXHead(RoIHeadTemplate):
+    """roi_mix_head.py:17-122 on the shared template (roi_head_template.py)."""
+
+    def __init__(self, in_channels=None, model_cfg=None, num_class=1, code_size=7, add_box_param=False, test_cfg=None,
+                 mixer_type=None, num_patches=49, **kwargs):
+        super().__init__(num_class=num_class, model_cfg=model_cfg)
+        if in_channels is None:
+            in_channels = kwargs.pop("input_channels")          # the legacy configs' name for it
+        self.test_cfg = test_cfg
+        self.code_size, self.add_box_param, self.num_patches = code_size, add_box_param, num_patches
+        if mixer_type == "MLPMixer":
+            self.mlp_mixer = MLPMixer(in_channels=in_channels, num_patches=num_patches)
+        elif mixer_type == "ResMLP":
+            self.mlp_mixer = ResMLPLayer(in_channels=in_channels, num_patches=num_patches)
+        else:
+            self.mlp_mixer = nn.Sequential()
+        pre = in_channels * num_patches
+        shared, fcs = [], list(model_cfg["SHARED_FC"])
+        for k, c in enumerate(fcs):
+            shared += [nn.Conv1d(pre, c, kernel_size=1, bias=False), build_norm_layer(_BN1, c)[1], nn.ReLU()]
+            pre = c
+            if k != len(fcs) - 1 and model_cfg["DP_RATIO"] > 0:
+                shared.append(nn.Dropout(model_cfg["DP_RATIO"]))
+        self.shared_fc_layer = nn.Sequential(*shared)
+        self.cls_layers = self.make_fc_layers(pre, num_class, model_cfg["CLS_FC"])
+        self.reg_layers = self.make_fc_layers(pre, code_size, model_cfg["REG_FC"])
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
 
     def _forward_train(self, batch_dict):
         """roi_mix_head.py:81-121 with training=True: the module path (BatchNorm statistics, Dropout)."""
@@ -654,6 +749,116 @@ class RoIMIXHead(nn.Module):
         c, b = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"], cls, reg)
         batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"] = c, b
         batch_dict["cls_preds_normalized"] = False
+        return batch_dict
+
+
+class FFN(nn.Module):
+    """mmcv.cnn.bricks.transformer.FFN as roi_ffn_head.py:34-39 constructs it (mmcv is a third-party package that
+    is not installed here: restated from its published definition).  num_fcs Linear layers -- the first
+    num_fcs - 1 widen to `feedforward_channels` with activation + dropout -- and the input added back.
+    Parameter names as in mmcv: layers.<i>.0.{weight,bias} for the widening layers, layers.<num_fcs-1>.{weight,bias}
+    for the last."""
+
+    def __init__(self, embed_dims, feedforward_channels, num_fcs=2, act_cfg=None, dropout=0.0, add_residual=True):
+        super().__init__()
+        assert num_fcs >= 2, f"num_fcs should be no less than 2. got {num_fcs}."
+        act = dict(act_cfg or dict(type="ReLU", inplace=True))
+        kind = act.pop("type")
+        if kind not in ("ReLU", "GELU"):
+            raise NotImplementedError(f"FFN activation {kind}")
+        layers, c = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(c, feedforward_channels),
+                                        nn.ReLU(**act) if kind == "ReLU" else nn.GELU(), nn.Dropout(dropout)))
+            c = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        self.layers = nn.Sequential(*layers)
+        self.dropout = nn.Dropout(dropout)
+        self.add_residual = add_residual
+
+    def forward(self, x, residual=None):
+        out = self.dropout(self.layers(x))
+        if not self.add_residual:
+            return out
+        return (x if residual is None else residual) + out
+
+
+@ROI_HEAD.register_module
+class RoIFFNHead(RoIHeadTemplate):
+    """roi_ffn_head.py:10-140: a transformer-style feed-forward block + LayerNorm over the flattened RoI feature,
+    then Linear + LayerNorm + ReLU towers for class, box residual and (num_iou_fcs > 0) an IoU estimate."""
+
+    def __init__(self, model_cfg, num_cls_fcs=1, num_reg_fcs=1, num_iou_fcs=1, feedforward_channels=2048,
+                 content_dim=256, num_ffn_fcs=2, dropout=0.0, ffn_act_cfg=dict(type="ReLU", inplace=True),
+                 num_class=1, code_size=7, test_cfg=None, init_bias=-2.19, add_box_param=False):
+        super().__init__(num_class=num_class, model_cfg=model_cfg)
+        self.test_cfg, self.code_size, self.add_box_param, self.init_bias = test_cfg, code_size, add_box_param, init_bias
+        self.use_iou = num_iou_fcs > 0
+        self.ffn = FFN(content_dim, feedforward_channels, num_ffn_fcs, act_cfg=ffn_act_cfg, dropout=dropout)
+        self.ffn_norm = build_norm_layer(dict(type="LN"), content_dim)[1]
+
+        def tower(n):
+            mods = nn.ModuleList()
+            for _ in range(n):
+                mods += [nn.Linear(content_dim, content_dim, bias=True), build_norm_layer(dict(type="LN"), content_dim)[1],
+                         nn.ReLU()]
+            return mods
+
+        self.cls_fcs = tower(num_cls_fcs)
+        self.fc_cls = nn.Linear(content_dim, self.num_class)
+        self.reg_fcs = tower(num_reg_fcs)
+        self.fc_reg = nn.Linear(content_dim, code_size)
+        if self.use_iou:
+            self.iou_fcs = tower(num_iou_fcs)
+            self.fc_iou = nn.Linear(content_dim, 1)
+        self.init_weights()
+
+    @torch.no_grad()
+    def init_weights(self):
+        """roi_ffn_head.py:66-79."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                m.reset_parameters()
+                nn.init.xavier_uniform_(m.weight)
+        nn.init.zeros_(self.fc_reg.weight)
+        nn.init.zeros_(self.fc_reg.bias)
+        nn.init.constant_(self.fc_cls.bias, self.init_bias)
+        if self.use_iou:
+            nn.init.zeros_(self.fc_iou.weight)
+            nn.init.zeros_(self.fc_iou.bias)
+
+    def forward(self, batch_dict, training=True):
+        """roi_ffn_head.py:81-140."""
+        if training:
+            td = batch_dict.get("roi_targets_dict", None)
+            if td is None:
+                td = self.assign_targets(batch_dict)
+                batch_dict["rois"], batch_dict["roi_labels"], batch_dict["roi_scores"] = td["rois"], td["roi_labels"], td["roi_scores"]
+        if self.add_box_param:
+            batch_dict["roi_features"] = torch.cat([batch_dict["roi_features"], batch_dict["rois"],
+                                                    batch_dict["roi_scores"].unsqueeze(-1)], dim=-1)
+        batch_dict["roi_features"] = batch_dict["roi_features"].view(-1, batch_dict["roi_features"].shape[-1])
+        query = self.ffn_norm(self.ffn(batch_dict["roi_features"]))
+
+        def run(layers, x):
+            for m in layers:
+                x = m(x)
+            return x
+
+        rcnn_cls = self.fc_cls(run(self.cls_fcs, query))
+        rcnn_reg = self.fc_reg(run(self.reg_fcs, query))
+        rcnn_iou = self.fc_iou(run(self.iou_fcs, query)) if self.use_iou else None
+        if not training:
+            c, b = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"], rcnn_cls, rcnn_reg)
+            batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"] = c, b
+            batch_dict["cls_preds_normalized"] = False
+            return batch_dict
+        td["rcnn_cls"], td["rcnn_reg"] = rcnn_cls, rcnn_reg
+        if self.use_iou:
+            td["rcnn_iou"] = rcnn_iou
+            _, td["batch_box_preds"] = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"],
+                                                                     rcnn_cls, rcnn_reg)
+        self.forward_ret_dict = td
         return batch_dict
 
 

@@ -119,6 +119,8 @@ def _launch_conv(dt, feats, cin, nbr, stride, num, cap, w, scale, shift, res, re
         e1.record(torch.cuda.current_stream(dev))
         EVENT_PROBE["events"].append((e0, e1))
         EVENT_PROBE["rules"], EVENT_PROBE["rows"] = nbr, num
+    if _lib.FLOP_LOG is not None:
+        _lib.log_flops(f"sparse {cin}->{cout}", cin, cout, (nbr[:, :int(num.item())] >= 0).sum())
     _lib.check(rc, "pn_spconv_forward")
 
 

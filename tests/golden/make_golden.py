@@ -15,6 +15,7 @@ Reference code executed here (imported from /root/reference, nothing copied):
   detectors.pillar_rcnn.PillarRCNN.post_process       -> rcnn.npz
   det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz
   roi_heads ProposalTargetLayer / RoIHeadTemplate.assign_targets + get_loss, PointHead targets + loss -> rcnn_train.npz
+  second_stage BEVFeature, roi_heads RoIFFNHead (without mmcv's FFN block) / RoIHead training -> rcnn_extra.npz
   det3d.ops.point_cloud.point_cloud_ops.points_to_voxel (interpreted)  -> voxelize.npz
   det3d.torchie.parallel.collate.collate_kitti                         -> collate.json
 
@@ -632,6 +633,154 @@ def golden_rcnn_train():
     save("rcnn_train.npz", **arrays)
 
 
+def golden_rcnn_extra():
+    """The second-stage classes no live config names, from the reference's own modules (torch-CPU):
+    SECOND_STAGE.BEVFeature (two layouts whose laterals are dense), ROI_HEAD.RoIFFNHead (inference, and training with
+    its IoU branch: RoIHeadTemplate.get_box_iou_layer_loss), ROI_HEAD.RoIHead (training branch).
+    mmcv is not installed: RoIFFNHead's `FFN` block is served by this repository's restatement of it, so the fixture
+    pins everything of that head EXCEPT the FFN block.  boxes_aligned_iou3d_gpu (CUDA-only) is served by the
+    reference's arithmetic around the compiled-reference-pinned BEV overlap."""
+    from oracle import iou3d
+    from pillarnet_lts_amd.second_stage import FFN
+    for name in ("mmcv", "mmcv.cnn", "mmcv.cnn.bricks", "mmcv.cnn.bricks.transformer"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules.setdefault(name, m)
+    sys.modules["mmcv.cnn.bricks.transformer"].FFN = FFN
+    import det3d.ops.iou3d_nms.iou3d_nms_utils as iu
+    import det3d.models.roi_heads.target_assigner.proposal_target_layer as ptl
+    from det3d.models.second_stage.bev_interpolation import BEVFeature
+    from det3d.models.roi_heads.roi_ffn_head import RoIFFNHead
+    from det3d.models.roi_heads.roi_head import RoIHead
+    from det3d.torchie import Config
+
+    def boxes_iou3d_cpu(a, b):
+        a, b = iu.to_pcdet(a), iu.to_pcdet(b)
+        ov = torch.from_numpy(iou3d.iou_matrix(a.numpy(), b.numpy(), overlap_only=True)).float()
+        hmax = torch.min((a[:, 2] + a[:, 5] / 2).view(-1, 1), (b[:, 2] + b[:, 5] / 2).view(1, -1))
+        hmin = torch.max((a[:, 2] - a[:, 5] / 2).view(-1, 1), (b[:, 2] - b[:, 5] / 2).view(1, -1))
+        o3 = ov * torch.clamp(hmax - hmin, min=0)
+        va, vb = (a[:, 3] * a[:, 4] * a[:, 5]).view(-1, 1), (b[:, 3] * b[:, 4] * b[:, 5]).view(1, -1)
+        return o3 / torch.clamp(va + vb - o3, min=1e-6)
+
+    def boxes_aligned_iou3d_cpu(a, b):          # iou3d_nms_utils.py:77-116 with the overlap from the C oracle
+        return torch.diagonal(boxes_iou3d_cpu(a, b)).reshape(-1, 1).contiguous() if a.shape[0] else a.new_zeros((0, 1))
+
+    ptl.boxes_iou3d_gpu = boxes_iou3d_cpu
+    iu.boxes_aligned_iou3d_gpu = boxes_aligned_iou3d_cpu
+    arrays = {}
+    g = torch.Generator().manual_seed(61)
+    rng, pillar = [-6.4, -4.8, -2.0, 6.4, 4.8, 4.0], 0.1
+    B, R = 2, 10
+    rois = torch.zeros(B, R, 7)
+    rois[..., 0] = (torch.rand(B, R, generator=g) - 0.5) * 13.2
+    rois[..., 1] = (torch.rand(B, R, generator=g) - 0.5) * 10.0
+    rois[..., 2] = torch.randn(B, R, generator=g) * 0.3
+    rois[..., 3:6] = torch.rand(B, R, 3, generator=g) * 4.0 + 0.4
+    rois[..., 6] = (torch.rand(B, R, generator=g) - 0.5) * 6.6
+    rois[1, -2:] = 0
+    arrays["bevf.in.rois"] = rois.numpy()
+    arrays["meta.pc_range"], arrays["meta.pillar"] = np.asarray(rng), np.asarray(pillar)
+    for tag, out_stride in (("s4", 4), ("s8", 8)):
+        torch.manual_seed(62 + out_stride)
+        bev = BEVFeature(feature_sources=["conv4"], pillar_size=pillar, pc_range=rng, out_stride=out_stride, grid_size=5,
+                         in_channels=24, share_channels=16, backbone_channels=dict(conv1=32, conv2=64, conv3=128, conv4=256),
+                         backbone_strides=dict(conv1=1, conv2=2, conv3=4, conv4=8)).eval()
+        randomize_bn(bev, 6 + out_stride)
+        assert bev.lat_tensor_type == ["dense"]
+        H8, W8 = int(round(9.6 / pillar / 8)), int(round(12.8 / pillar / 8))
+        ex = dict(rois=rois.clone(), batch_size=B, bev_feature=torch.randn(B, 24, H8, W8, generator=g),
+                  backbone_features=dict(conv4=torch.randn(B, 256, H8, W8, generator=g)))
+        arrays[f"bevf.{tag}.in.bev_feature"] = ex["bev_feature"].numpy()
+        arrays[f"bevf.{tag}.in.conv4"] = ex["backbone_features"]["conv4"].numpy()
+        with torch.no_grad():
+            ex = bev(ex)
+        arrays[f"bevf.{tag}.out.roi_features"] = ex["roi_features"].numpy()
+        arrays[f"bevf.{tag}.out.point_coords"] = ex["point_coords"].numpy()
+        arrays.update({f"sd.bevf.{tag}." + k: v for k, v in to_np(bev.state_dict()).items()})
+
+    # ---- RoIFFNHead: inference ----
+    cfg = Config(dict(CLASS_AGNOSTIC=True,
+                      TARGET_CONFIG=dict(ROI_PER_IMAGE=32, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                         CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.7, CLS_BG_THRESH=0.25,
+                                         CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.5),
+                      LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="L1", IOU_LOSS="L1",
+                                       LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_iou_weight=0.7,
+                                                         code_weights=[1.0] * 7))))._cfg_dict
+    torch.manual_seed(71)
+    ffn = RoIFFNHead(model_cfg=cfg, feedforward_channels=48, content_dim=32, num_class=1, code_size=7)
+    with torch.no_grad():
+        for prm in (ffn.fc_reg.weight, ffn.fc_reg.bias, ffn.fc_iou.weight, ffn.fc_iou.bias):
+            prm.add_(torch.randn(prm.shape, generator=g) * 0.2)      # zero-initialised in the reference
+        for m in ffn.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.add_(torch.randn(m.weight.shape, generator=g) * 0.1)
+                m.bias.add_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    arrays.update({"sd.ffn." + k: v for k, v in to_np(ffn.state_dict()).items()})
+    feats = torch.randn(B, R, 32, generator=g)
+    scores = torch.rand(B, R, generator=g)
+    labels = torch.randint(1, 4, (B, R), generator=g)
+    arrays.update({"ffn.in.roi_features": feats.numpy(), "ffn.in.roi_scores": scores.numpy(), "ffn.in.roi_labels": labels.numpy()})
+    ffn.eval()
+    with torch.no_grad():
+        out = ffn(dict(batch_size=B, rois=rois.clone(), roi_features=feats.clone(), roi_scores=scores, roi_labels=labels),
+                  training=False)
+    arrays["ffn.out.batch_cls_preds"] = out["batch_cls_preds"].numpy()
+    arrays["ffn.out.batch_box_preds"] = out["batch_box_preds"].numpy()
+
+    # ---- RoIFFNHead + legacy RoIHead: training (targets, forward, losses incl. the IoU branch) ----
+    t = np.load(os.path.join(HERE, "rcnn_train.npz"))
+    tin = lambda k: torch.from_numpy(t[k]).clone()
+    Bt = t["in.rois"].shape[0]
+
+    def batch():
+        return dict(batch_size=Bt, rois=tin("in.rois"), roi_scores=tin("in.roi_scores"), roi_labels=tin("in.roi_labels"),
+                    gt_boxes_and_cls=tin("in.gt_boxes_and_cls"))
+
+    ffn.train()
+    np.random.seed(7)
+    torch.manual_seed(8)
+    td = ffn.assign_targets(batch())
+    M = td["rois"].shape[1]
+    tfeats = torch.randn(Bt, M, 32, generator=g)
+    arrays["ffn.train.in.roi_features"] = tfeats.numpy()
+    bd = dict(batch_size=Bt, rois=td["rois"], roi_labels=td["roi_labels"], roi_scores=td["roi_scores"],
+              roi_targets_dict=td, roi_features=tfeats.clone())
+    ffn(bd, training=True)
+    loss, tb = ffn.get_loss()
+    fr = ffn.forward_ret_dict
+    arrays.update({"ffn.train.rcnn_cls": fr["rcnn_cls"].detach().numpy(), "ffn.train.rcnn_reg": fr["rcnn_reg"].detach().numpy(),
+                   "ffn.train.rcnn_iou": fr["rcnn_iou"].detach().numpy(),
+                   "ffn.train.batch_box_preds": fr["batch_box_preds"].detach().numpy(),
+                   "ffn.train.loss": np.asarray(float(loss)), "ffn.train.loss_cls": np.asarray(float(tb["rcnn_loss_cls"])),
+                   "ffn.train.loss_reg": np.asarray(float(tb["rcnn_loss_reg"])),
+                   "ffn.train.loss_iou": np.asarray(float(tb["rcnn_loss_iou"]))})
+    loss.backward()
+    arrays["ffn.train.grad.fc_iou.weight"] = ffn.fc_iou.weight.grad.numpy()
+    arrays["ffn.train.grad.ffn.layers.0.0.weight"] = ffn.ffn.layers[0][0].weight.grad.numpy()
+
+    hcfg = Config(dict(cfg, SHARED_FC=[32, 32], CLS_FC=[32, 32], REG_FC=[32, 32], DP_RATIO=0.0))._cfg_dict
+    torch.manual_seed(81)
+    head = RoIHead(input_channels=32, model_cfg=hcfg, num_class=1, code_size=7).train()
+    randomize_bn(head, 82)
+    arrays.update({"sd.roihead." + k: v for k, v in to_np(head.state_dict()).items()})
+    np.random.seed(7)
+    torch.manual_seed(8)
+    bd = batch()
+    bd["roi_features"] = None
+    td2 = head.assign_targets(bd)
+    bd = dict(rois=td2["rois"], roi_labels=td2["roi_labels"], roi_scores=td2["roi_scores"], roi_targets_dict=td2,
+              roi_features=tfeats.clone())
+    head(bd, training=True)
+    loss2, tb2 = head.get_loss()
+    arrays.update({"roihead.train.rcnn_cls": head.forward_ret_dict["rcnn_cls"].detach().numpy(),
+                   "roihead.train.rcnn_reg": head.forward_ret_dict["rcnn_reg"].detach().numpy(),
+                   "roihead.train.loss": np.asarray(float(loss2)),
+                   "roihead.train.loss_cls": np.asarray(float(tb2["rcnn_loss_cls"])),
+                   "roihead.train.loss_reg": np.asarray(float(tb2["rcnn_loss_reg"]))})
+    save("rcnn_extra.npz", **arrays)
+
+
 def golden_loading():
     """LoadPointCloudFromFile (nuScenes branch) / read_sweep of the reference on .bin sweeps written to a
     temporary directory from seeded arrays; the fixture keeps the arrays, the transforms, the order the
@@ -769,3 +918,4 @@ if __name__ == "__main__":
     golden_rcnn()
     golden_loading()
     golden_rcnn_train()
+    golden_rcnn_extra()

@@ -65,3 +65,21 @@ def assert_detections_match(got, want, min_gap, gap_tol=2e-4, max_flips=6, score
     flips = unmatched_w + int((~used).sum())
     assert flips <= max_flips, f"{flips} detections differ; a borderline IoU explains at most {max_flips}"
     return flips
+
+
+def partner_rate(got, want, centre_tol=5e-2, score_tol=2e-2):
+    """Fraction of `want`'s detections (dict of numpy arrays: box3d_lidar, scores, label_preds) that have a partner in
+    `got`: same label, centre (x, y) within `centre_tol` metres, score within `score_tol`; each row of `got` serves once.
+    -> (rate, matched, total)."""
+    gb, gs, gl = np.asarray(got["box3d_lidar"]), np.asarray(got["scores"]), np.asarray(got["label_preds"])
+    wb, ws, wl = np.asarray(want["box3d_lidar"]), np.asarray(want["scores"]), np.asarray(want["label_preds"])
+    used, hit = np.zeros(gb.shape[0], bool), 0
+    for i in np.argsort(-ws):
+        ok = (gl == wl[i]) & (np.abs(gb[:, :2] - wb[i, :2]).max(1) <= centre_tol) & (np.abs(gs - ws[i]) <= score_tol) & ~used
+        j = np.flatnonzero(ok)
+        if j.size:
+            j = j[np.argmin(np.abs(gb[j, :2] - wb[i, :2]).max(1))]
+            used[j] = True
+            hit += 1
+    n = wb.shape[0]
+    return (hit / n if n else 1.0), hit, n

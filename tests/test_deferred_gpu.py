@@ -66,6 +66,34 @@ def test_frame_graph_replays_match_eager(lanes):
                 _same(w, h.result())
 
 
+def test_bench_shape_two_lane_graphs_match_eager():
+    """The exact shape bench.py times: BASELINE configs[1] frames (10 sweeps x 30 000 points, 1440^2 grid), bf16,
+    FrameGraphs(lanes=2) under its shared-CU tile policy, four distinct frames cycled with two in flight (a frame is
+    queued before the host takes the oldest one's detections) -- against the eager synchronous call, bit for bit."""
+    from pillarnet_lts_amd import FrameGraphs, presets, synth
+    torch.manual_seed(0)
+    cfg = presets.nusc_pillarnet18()
+    model = presets.build(cfg)
+    synth.randomize_bn_(model, seed=1)
+    model.to_inference(torch.bfloat16)
+    frames = [torch.from_numpy(synth.nusc_frame(10, 30000, seed=i)).cuda() for i in range(4)]
+    examples = [{"points": [f], "metadata": [{"token": i}]} for i, f in enumerate(frames)]
+    with torch.no_grad():
+        want = [model(e, return_loss=False) for e in examples]
+        assert all(w[0]["scores"].shape[0] > 100 for w in want)
+        runner = FrameGraphs(model, lanes=2)
+        inflight, got = [], []
+        for i in range(12):
+            inflight.append((i % 4, runner.forward_deferred(examples[i % 4])))
+            if len(inflight) > 2:
+                k, h = inflight.pop(0)
+                got.append((k, h.result()))
+        got += [(k, h.result()) for k, h in inflight]
+    assert len(got) == 12
+    for k, out in got:
+        _same(want[k], out)
+
+
 def test_frame_graph_capture_beside_a_live_process_group():
     """what every rank of `bench.py --gpus N` does: an RCCL process group (its watchdog thread polling events) is
     alive while the frame graphs are captured and replayed; collectives before and after still work"""

@@ -120,6 +120,12 @@ def test_fp32_end_to_end_detections(cuda, built):
         assert hit >= 0.95 * want["box3d_lidar"].shape[0], (hit, want["box3d_lidar"].shape[0])
 
 
+# measured on MI355X: 0.869 (hip) / 0.866 (miopen); the bar is that minus a margin.  (Random-init heat maps are nearly
+# flat, so ranks flip under bf16 noise: tests/test_fullsize_gpu.py holds the detection-level comparison on a
+# well-conditioned model.)
+BF16_REDUCED_BAR = 0.84
+
+
 @pytest.mark.parametrize("backend", ["hip", "miopen"])
 def test_bf16_bev_map(cuda, built, backend):
     cfg, model, sd, test_cfg, pts, dets, mid = built
@@ -145,7 +151,9 @@ def test_bf16_bev_map(cuda, built, backend):
     got_b, lab = out[0]["box3d_lidar"].cpu().numpy(), out[0]["label_preds"].cpu().numpy()
     hit = sum(bool(((np.abs(got_b[:, :2] - want["box3d_lidar"][i, :2]).max(1) < 5e-2) &
                     (lab == want["label_preds"][i])).any()) for i in range(want["box3d_lidar"].shape[0]))
-    assert hit >= 0.8 * want["box3d_lidar"].shape[0], (hit, want["box3d_lidar"].shape[0])
+    n = want["box3d_lidar"].shape[0]
+    print(f"\n[{backend}] reduced-range bf16 detections with a partner (label, centre 5 cm): {hit}/{n} = {hit / n:.3f}")
+    assert hit >= BF16_REDUCED_BAR * n, (hit, n)
     model.to_inference(torch.float32)
 
 

@@ -15,9 +15,9 @@ import numpy as np
 import pytest
 import torch
 
-from fullsize_cases import KINDS, build_model, sha, state_sha
+from fullsize_cases import KINDS, apply_calibration, build_model, sha, state_sha
 from oracle import detector_oracle as do
-from parity_util import assert_detections_match
+from parity_util import assert_detections_match, partner_rate
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -145,6 +145,70 @@ def test_bf16_full_size_within_stated_tolerance(cuda, kind):
     ctr = d["box3d_lidar"][:, :3].cpu().numpy()
     assert (ctr >= np.asarray(lim[:3], np.float32)).all() and (ctr <= np.asarray(lim[3:], np.float32)).all()
     first.to_inference(torch.float32)
+
+
+# Bars, against what scripts/bf16_match_rate.py measured on MI355X (nusc / nusc1 / waymo / rcnn):
+#   fp32, partner = same label, centre <= 5 cm, score <= 2e-2:                  1.000 on every case
+#   bf16, same label + centre <= 5 cm (the box is there):                        0.978 / 0.976 / 0.966 / 0.975
+#   bf16, ... and score <= 5e-2:                                                 0.956 / 0.966 / 0.916 / 0.964
+#   bf16, ... and score <= 2e-2 (printed, not asserted):                         0.795 / 0.843 / 0.714 / 0.783
+# The boxes without a partner sit at the post-NMS cap (the 83rd / 200th score of a task); centres of the others agree to
+# <= 1.5 cm.  The bf16 score error (median 0.007, 90 % <= 0.03-0.036, max 0.06-0.09) is the 1 % relative error of the bf16
+# BEV map seen through heat-map logits that span about +-10.
+FP32_BAR = 0.98
+BF16_PRESENT_BAR = 0.95
+BF16_SCORE_TOL, BF16_BAR = 5e-2, 0.90
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_calibrated_model_detections_match_oracle_in_fp32_and_bf16(cuda, kind):
+    """Detection-level parity at full size on a model that behaves numerically like a trained one (BatchNorm statistics
+    calibrated on the frame, head outputs of O(1), peaked heat maps: fullsize_cases.apply_calibration) against the fp32
+    oracle's detections on that model (tests/golden/fullsize_<kind>_calibrated.npz).  fp32: every oracle detection has
+    a partner (same label, centre within 5 cm, score within 2e-2; bar 98 %).  bf16 -- the benchmarked dtype, through
+    PillarNet.forward (ranked lazy head) and, for the benchmarked nuScenes frame, through the two-lane frame graphs
+    (bit-identical to eager) -- >= 95 % of the oracle's boxes are present (label, centre within 5 cm) and >= 90 % also
+    agree in score to 5e-2; all rates are printed.  Also bounds the bf16 BEV map error on this model (3e-2)."""
+    from pillarnet_lts_amd import FrameGraphs
+    _cache.clear()
+    cfg, model, first_cfg, first, pts = build_model(kind)
+    g = np.load(os.path.join(G, f"fullsize_{kind}_calibrated.npz"))
+    assert np.array_equal(sha(pts), g["points_sha"]) and np.array_equal(state_sha(model.state_dict()), g["weights_sha"])
+    apply_calibration(first, g)
+    want = dict(box3d_lidar=g["det_boxes"], scores=g["det_scores"], label_preds=g["det_labels"])
+    assert want["scores"].shape[0] >= 200 and float(np.quantile(want["scores"], 0.9)) > 0.5      # a spread-out score field
+    ex = {"points": [torch.from_numpy(pts).to(cuda)], "metadata": [None]}
+    host = lambda d: {k: d[k].float().cpu().numpy() if k != "label_preds" else d[k].cpu().numpy()
+                      for k in ("box3d_lidar", "scores", "label_preds")}
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-6))
+    with torch.no_grad():
+        first.to_inference(torch.float32)
+        r32, hit, n = partner_rate(host(first(ex, return_loss=False)[0]), want)
+        print(f"\n[{kind}] fp32 product vs fp32 oracle: {hit}/{n} = {r32:.3f}")
+        assert r32 >= FP32_BAR, (kind, hit, n)
+        first.to_inference(torch.bfloat16)
+        bev, _ = first.extract_feat(ex)
+        for k in range(len(bev)):
+            r = rel(cells_of(bev[k], g[f"bev{k}_cells"]), g[f"bev{k}_vals"])
+            print(f"[{kind}] bf16 BEV map {k}: relative L2 {r:.4f}")
+            assert r <= 3e-2, (kind, k, r)
+        eager = first(ex, return_loss=False)[0]
+        r16, hit, n = partner_rate(host(eager), want, score_tol=BF16_SCORE_TOL)
+        rp, hitp, _ = partner_rate(host(eager), want, score_tol=2.0)
+        print(f"[{kind}] bf16 product vs fp32 oracle: present {hitp}/{n} = {rp:.3f}; score within {BF16_SCORE_TOL}: {hit}/{n} = {r16:.3f}")
+        assert rp >= BF16_PRESENT_BAR, (kind, hitp, n)
+        r16s, hits, _ = partner_rate(host(eager), want, score_tol=2e-2)
+        print(f"[{kind}] bf16 product vs fp32 oracle, score within 2e-2: {hits}/{n} = {r16s:.3f}")
+        assert r16 >= BF16_BAR, (kind, hit, n)
+        if kind == "nusc":               # the path bench.py times: HIP-graph replays, two frames in flight
+            graphs = FrameGraphs(first, lanes=2)
+            handles = [graphs.forward_deferred(ex) for _ in range(4)]
+            for h in handles:
+                out = h.result()[0]
+                for key in ("box3d_lidar", "scores", "label_preds"):
+                    assert torch.equal(out[key], eager[key]), key
+            print(f"[{kind}] bf16 two-lane frame graphs: bit-identical to eager, rate {r16:.3f}")
+    del first, model
 
 
 def test_pillarrcnn_second_stage_full_size_matches_oracle(cuda):

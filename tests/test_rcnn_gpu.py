@@ -367,3 +367,70 @@ def test_pillarrcnn_train_step(cuda):
         v, _ = solver.train_step(model, ex, opt, sch, step)
         vals.append(v)
     assert all(np.isfinite(vals)) and min(vals[-2:]) < vals[0], vals
+
+
+@pytest.mark.parametrize("tag,out_stride", [("s4", 4), ("s8", 8)])
+def test_bev_feature_matches_reference_outputs(cuda, tag, out_stride):
+    """SECOND_STAGE.BEVFeature (bev_interpolation.py:17-159) against the reference's own module run on CPU
+    (tests/golden/rcnn_extra.npz): the fp32 module path + the HIP RoI pooling within 1e-3."""
+    g = np.load(os.path.join(G, "rcnn_extra.npz"))
+    rng, pillar = [float(v) for v in g["meta.pc_range"]], float(g["meta.pillar"])
+    bev = _load(second_stage.BEVFeature(
+        feature_sources=["conv4"], pillar_size=pillar, pc_range=rng, out_stride=out_stride, grid_size=5, in_channels=24,
+        share_channels=16, backbone_channels=dict(conv1=32, conv2=64, conv3=128, conv4=256),
+        backbone_strides=dict(conv1=1, conv2=2, conv3=4, conv4=8)), g, f"sd.bevf.{tag}.").to(cuda)
+    t = lambda k: torch.from_numpy(g[k]).to(cuda)
+    B = g["bevf.in.rois"].shape[0]
+    ex = dict(rois=t("bevf.in.rois"), batch_size=B, bev_feature=t(f"bevf.{tag}.in.bev_feature"),
+              backbone_features=dict(conv4=t(f"bevf.{tag}.in.conv4")))
+    with torch.no_grad():
+        out = bev(dict(ex))
+        np.testing.assert_allclose(out["point_coords"].cpu().numpy(), g[f"bevf.{tag}.out.point_coords"], atol=4e-6)
+        np.testing.assert_allclose(out["roi_features"].cpu().numpy(), g[f"bevf.{tag}.out.roi_features"], atol=1e-3, rtol=1e-3)
+        assert out["point_features"].shape == (B, g["bevf.in.rois"].shape[1], 25, 16)
+
+
+@pytest.mark.parametrize("out_stride", [4, 8])
+def test_bev_feature_bf16_plan_close_to_fp32_modules(cuda, out_stride):
+    """BEVFeature's map fusion on the bf16 gather-GEMM plan (2x2 stride-2 / 1x1 transposed convs into channel slices,
+    one 3x3 fusion launch) against its own torch modules in fp32; widths the kernels take (multiples of 32)."""
+    torch.manual_seed(4)
+    bev = second_stage.BEVFeature(
+        feature_sources=["conv4"], pillar_size=0.1, pc_range=[-6.4, -4.8, -2.0, 6.4, 4.8, 4.0], out_stride=out_stride,
+        grid_size=5, in_channels=64, share_channels=32, backbone_channels=dict(conv1=32, conv2=64, conv3=128, conv4=256),
+        backbone_strides=dict(conv1=1, conv2=2, conv3=4, conv4=8)).to(cuda).eval()
+    synth.randomize_bn_(bev, seed=3)
+    g = torch.Generator().manual_seed(5)
+    rois = torch.from_numpy(_rois(np.random.RandomState(2), 2, 9, 5.0)).to(cuda)
+    x = torch.randn(2, 64, 12, 16, generator=g).to(cuda).to(torch.bfloat16)
+    c4 = torch.randn(2, 256, 12, 16, generator=g).to(cuda).to(torch.bfloat16)
+    with torch.no_grad():
+        want = bev(dict(rois=rois, bev_feature=x.float(), backbone_features=dict(conv4=c4.float())))["roi_features"]
+        bev._dense_hip = True
+        assert bev._hip_plan_fits()
+        got = bev(dict(rois=rois, bev_feature=x, backbone_features=dict(conv4=c4)))["roi_features"]
+    rel = float((got - want).norm() / want.norm())
+    assert 0 < rel < 1e-2, rel
+
+
+def test_roi_iou_branch_loss_on_hip_iou(cuda):
+    """RoIHeadTemplate's IoU branch (roi_head_template.py:117-147) with the rotated 3-D IoU from the HIP kernel
+    against the reference-generated loss (there the IoU came from the pinned C oracle): 1e-4 relative."""
+    g, t = np.load(os.path.join(G, "rcnn_extra.npz")), np.load(os.path.join(G, "rcnn_train.npz"))
+    cfg = ConfigDict(dict(CLASS_AGNOSTIC=True,
+                          TARGET_CONFIG=dict(ROI_PER_IMAGE=32, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                             CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.7, CLS_BG_THRESH=0.25,
+                                             CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.5),
+                          LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="L1", IOU_LOSS="L1",
+                                           LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0,
+                                                             rcnn_iou_weight=0.7, code_weights=[1.0] * 7))))
+    head = _load(second_stage.RoIFFNHead(model_cfg=cfg, feedforward_channels=48, content_dim=32, num_class=1, code_size=7),
+                 g, "sd.ffn.").to(cuda).train()
+    tt = lambda a, k: torch.from_numpy(a[k]).to(cuda)
+    td = {k: tt(t, "pt." + k) for k in ("rois", "gt_of_rois", "gt_of_rois_src", "roi_scores", "roi_labels", "reg_valid_mask",
+                                          "rcnn_cls_labels")}
+    head(dict(batch_size=2, rois=td["rois"], roi_labels=td["roi_labels"], roi_scores=td["roi_scores"], roi_targets_dict=td,
+              roi_features=tt(g, "ffn.train.in.roi_features")), training=True)
+    loss, tb = head.get_loss()
+    np.testing.assert_allclose(float(tb["rcnn_loss_iou"]), float(g["ffn.train.loss_iou"]), rtol=1e-4)
+    np.testing.assert_allclose(float(loss.detach()), float(g["ffn.train.loss"]), rtol=1e-4)
