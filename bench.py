@@ -183,6 +183,28 @@ def _dist_setup(args):
     return world, rank, local, dist
 
 
+def _ranks_seen(dist, dev):
+    """How many ranks the collective library actually connects: an all-reduce of ones (RCCL on the GPU, gloo in the
+    dry run), not the environment's WORLD_SIZE."""
+    import torch
+    if dist is None:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=dev if dev is not None else "cpu")
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
+def _min_max_over_ranks(dist, value, dev):
+    import torch
+    if dist is None:
+        return value, value
+    lo = torch.tensor([value], dtype=torch.float64, device=dev if dev is not None else "cpu")
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())
+
+
 def _max_over_ranks(dist, seconds, dev):
     import torch
     if dist is None:
@@ -205,9 +227,10 @@ def run_dry(args):
         x = x * 1.0
     barrier()
     elapsed = _max_over_ranks(dist, time.perf_counter() - t0, None)
+    ranks_seen = _ranks_seen(dist, None)
     if rank == 0:
         print(json.dumps({"metric": "frames/sec, nuScenes 10-sweep PillarNet-18 inference", "dry_run": True,
-                          "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "value": None, "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 6),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                           "data": "none (launcher dry run on CPU, gloo)", "mode": args.mode,
@@ -271,8 +294,11 @@ def run_infer(args):
                 out = inflight.pop(0).result()
         for h in inflight:
             out = h.result()
+        own = time.perf_counter() - t0            # this rank's own stream of frames (before the closing barrier)
         barrier()
         elapsed = _max_over_ranks(dist, time.perf_counter() - t0, dev)
+        rank_fps = _min_max_over_ranks(dist, args.steps / own, dev)
+        ranks_seen = _ranks_seen(dist, dev)
 
         # the same frames with the host waiting after each one (the shape of dist_test.py's loop)
         barrier()
@@ -437,6 +463,8 @@ def run_infer(args):
                        "detections_last_frame": int(out[0]["scores"].shape[0])},
             "loop": (f"one HIP graph replay per frame, {args.lanes} frames in flight on {args.lanes} streams; " if not args.no_graph else "") +
                     "frames queued ahead of the host's wait for the oldest frame's detections (forward_deferred)",
+            "ranks_seen": ranks_seen,
+            "per_rank_frames_per_s": {"min": round(rank_fps[0], 3), "max": round(rank_fps[1], 3)},
             "value_host_wait_per_frame": round(frames_total / elapsed_sync, 3),
             "value_h2d_inclusive": round(frames_total / elapsed_h2d, 3),
             "roofline": roof,
@@ -478,14 +506,24 @@ def run_train(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    from pillarnet_lts_amd import nn_utils
     for step in range(args.warmup):
         trainer.step(ex, step)
     barrier()
+    torch.cuda.reset_peak_memory_stats()
+    early0 = trainer.buckets.launched_early if trainer.buckets is not None else 0
+    bn0 = nn_utils.SYNC_BN_COLLECTIVES[0]
     t0 = time.perf_counter()
     for step in range(args.warmup, args.warmup + args.steps):
         loss, _ = trainer.step(ex, step)
+    own = time.perf_counter() - t0
     barrier()
     elapsed = _max_over_ranks(dist, time.perf_counter() - t0, dev)
+    rank_sps = _min_max_over_ranks(dist, args.steps * per_gpu / own, dev)
+    ranks_seen = _ranks_seen(dist, dev)
+    n_buckets = len(trainer.buckets.buckets) if trainer.buckets is not None else 0
+    early = (trainer.buckets.launched_early - early0) / max(args.steps, 1) if trainer.buckets is not None else 0
+    bn_coll = (nn_utils.SYNC_BN_COLLECTIVES[0] - bn0) / max(args.steps, 1)
 
     # the gradient exchange alone: one flat all-reduce of the same byte count, bus bandwidth per the
     # ring formula 2 (N-1)/N * bytes / t against one xGMI link (~153 GB/s)
@@ -517,6 +555,11 @@ def run_train(args):
                        "parallelism": f"dp{world}", "sync_bn": trainer.sync_bn, "overlap": trainer.overlap,
                        "loss_last_step": round(float(loss), 4),
                        "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
+            "ranks_seen": ranks_seen,
+            "per_rank_samples_per_s": {"min": round(rank_sps[0], 3), "max": round(rank_sps[1], 3)},
+            "gradient_buckets": {"count": n_buckets, "launched_early_per_step": round(early, 2),
+                                 "note": "buckets all-reduced while backward was still running (the rest at finish())"},
+            "sync_bn_collectives_per_step": round(bn_coll, 1),
             "allreduce": allreduce}), flush=True)
     if dist is not None:
         dist.destroy_process_group()

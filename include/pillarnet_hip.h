@@ -126,8 +126,12 @@ int pn_nms_normal(const float* boxes, int n, float thresh, int post_max, int32_t
  * counterpart in the reference (whose nms_gpu calls cudaMalloc / cudaFree per call,
  * iou3d_nms.cpp:125-137).  The suppression bit matrix lives in a PN_NMS_STATIC_BYTES array inside
  * the library's device image (one copy per GPU, held until the process ends); the call allocates
- * and frees nothing.  Limit: pn_nms_workspace_bytes(num_sets, cap) <= PN_NMS_STATIC_BYTES
- * (16 sets of 1024 boxes, or one set of 4096), otherwise PN_ENOSPC.  Every call on a GPU uses
+ * and frees nothing.  Limit: the bit matrix alone must fit, num_sets * cap * ceil(cap / 64) * 8 <=
+ * PN_NMS_STATIC_BYTES and cap <= 4096 (16 sets of 1024 boxes, or one set of 4096), otherwise PN_ENOSPC
+ * (pn_nms_workspace_bytes is NOT the bound: it also counts the geometry block and the clip queue that
+ * only pn_nms_rotated's workspace holds).  Without that queue the polygon clips run inside the
+ * 64 x 64 tiles instead of one pair per lane over the whole chip: same results, slower than
+ * pn_nms_rotated on sets with many overlapping pairs.  Every call on a GPU uses
  * that GPU's one array: calls that overlap on one GPU (two streams, two threads) race; calls
  * queued on one stream do not.  The first call on a device looks the array's address up
  * (hipGetSymbolAddress); make one call per device before capturing a graph. */
@@ -215,7 +219,7 @@ int pn_occupancy_from_indices(const int32_t* indices, const int32_t* count_dev, 
  * channel order  reg(2) height(1) dim(3) rot(2: sin, cos) [vel(2)] [iou(1)] hm(num_classes).
  * Output, per sample b: the kept boxes of its groups concatenated in group order --
  * out_boxes [B, out_cap, box_dim] (x,y,z,dx,dy,dz,[vx,vy,]heading), out_scores, out_labels
- * (int64 as the reference's label_preds, +label_offset), out_num[b].  *status bit 0: more than 4096 cells tied
+ * (int64 as the reference's label_preds, +label_offset), out_num[b].  *status bit 0: more cells than the 8192-slot candidate list holds tied
  * inside one score bin at the pre_max cut-off (excess dropped); bit 1: see pn_centerhead_detect_selected; bit 2: a
  * circle-NMS set had more cells above the score threshold than its pre_max (the reference ranks them all, here
  * the best pre_max).  Score ties are ordered by ascending cell index.

@@ -414,7 +414,7 @@ class CenterHead(nn.Module):
             return boxes, scores, labels, num
         counts = num.cpu().tolist()   # the frame's single device->host sync
         if counts[B] & 1:
-            self.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+            self.logger.warning("CenterHead.predict: more equal-score cells at the pre-NMS cut-off than the candidate list holds (8192); kept in ascending cell order")
         if counts[B] & 4:
             self.logger.warning("CenterHead.predict: circle NMS ranked the best 4096 cells of a task; more were above "
                                 "score_threshold (the reference ranks all of them)")
@@ -456,7 +456,7 @@ class PendingDetections:
             self.out, self.redo = self.redo(), None
             return self.out
         if counts[B] & 1:
-            head.logger.warning("CenterHead.predict: >4096 equal-score cells at the pre-NMS cut-off")
+            head.logger.warning("CenterHead.predict: more equal-score cells at the pre-NMS cut-off than the candidate list holds (8192); kept in ascending cell order")
         if counts[B] & 4:
             head.logger.warning("CenterHead.predict: circle NMS ranked the best 4096 cells of a task; more were above "
                                 "score_threshold (the reference ranks all of them)")

@@ -111,10 +111,15 @@ def load_checkpoint(model, filename, map_location=None, strict=False, logger=Non
     """checkpoint.py:166-217: read, find the state dict, strip a `module.` prefix (DDP saves),
     load non-strictly.  Returns the checkpoint dict (meta / optimizer for `resume`)."""
     checkpoint = _read(filename, map_location)
-    if isinstance(checkpoint, dict) and "state_dict" in checkpoint:
+    if isinstance(checkpoint, OrderedDict) and "state_dict" not in checkpoint:
+        state_dict = checkpoint        # any OrderedDict is a bare state dict to the reference (checkpoint.py:203-204)
+    elif isinstance(checkpoint, dict) and "state_dict" in checkpoint:
         state_dict = checkpoint["state_dict"]
-    elif isinstance(checkpoint, dict) and checkpoint and all(torch.is_tensor(v) for v in checkpoint.values()):
-        state_dict = checkpoint        # a bare state dict (an OrderedDict in the reference's test)
+    elif isinstance(checkpoint, dict) and checkpoint and "meta" not in checkpoint and "optimizer" not in checkpoint \
+            and any(torch.is_tensor(v) for v in checkpoint.values()):
+        # a bare state dict (the reference takes any OrderedDict, checkpoint.py:194-197): entries that are not tensors
+        # (a version counter some exporters add) are left to load_state_dict's unexpected-key report
+        state_dict = OrderedDict((k, v) for k, v in checkpoint.items() if torch.is_tensor(v))
     else:
         raise RuntimeError("No state_dict found in checkpoint file {}".format(filename))
     keys = list(state_dict.keys())
@@ -129,14 +134,24 @@ def weights_to_cpu(state_dict):
     return OrderedDict((k, v.detach().cpu()) for k, v in state_dict.items())
 
 
-def _plain(obj):
-    """Config dicts / tuples -> plain containers, so that the file loads under weights_only."""
+def _plain(obj, strict=False, where="meta"):
+    """Config dicts / tuples / numpy values -> plain containers and Python numbers, so that the file loads under
+    weights_only.  numpy scalars become Python numbers and numpy arrays tensors (an optimiser's hyper-parameters
+    must come back as numbers).  What is left over: `strict` raises (optimiser state -- a value silently turned into
+    text would break the optimiser a step after resume), otherwise it is stored as its text (free-form `meta`)."""
+    import numpy as np
     if isinstance(obj, dict):
-        return {(k if isinstance(k, (str, int)) else str(k)): _plain(v) for k, v in obj.items()}
+        return {(k if isinstance(k, (str, int)) else str(k)): _plain(v, strict, where) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
-        return [_plain(v) for v in obj]
+        return [_plain(v, strict, where) for v in obj]
+    if isinstance(obj, np.generic):           # (before the Python numbers: numpy.float64 is a subclass of float)
+        return obj.item()
     if isinstance(obj, (str, int, float, bool)) or obj is None or torch.is_tensor(obj):
         return obj
+    if isinstance(obj, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(obj))
+    if strict:
+        raise TypeError(f"{where}: cannot store a value of type {type(obj).__name__} in a checkpoint")
     return str(obj)
 
 
@@ -155,7 +170,7 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
         model = model.module
     checkpoint = {"meta": meta, "state_dict": weights_to_cpu(model.state_dict())}
     if optimizer is not None:
-        checkpoint["optimizer"] = _plain(optimizer.state_dict())
+        checkpoint["optimizer"] = _plain(optimizer.state_dict(), strict=True, where="optimizer state")
     torch.save(checkpoint, filename)
 
 

@@ -132,15 +132,22 @@ extern "C" int pn_spconv_wgrad(const float* x, int cin, int x_ld, const int32_t*
                                const int32_t* count_dev, int rows, const float* grad_out, int cout, int g_ld,
                                float* dw, void* workspace, size_t workspace_bytes, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !grad_out || !dw || rows < 0 || ntaps <= 0 || ntaps > 9) return PN_EINVAL;
-  if (cin % 32 != 0 || cout % 32 != 0 || cin <= 0 || cout <= 0) return PN_EINVAL;
-  if (!nbr && ntaps != 1) return PN_EINVAL;
+  PN_CHECK_ARG(x && grad_out && dw && rows >= 0 && ntaps >= 1 && ntaps <= 9,
+               "pn_spconv_wgrad: bad argument (null pointer, rows %d, taps %d)", rows, ntaps);
+  PN_CHECK_ARG(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0,
+               "pn_spconv_wgrad: channel widths %d -> %d must be multiples of 32", cin, cout);
+  PN_CHECK_ARG(nbr || ntaps == 1, "pn_spconv_wgrad: %d taps need a rulebook", ntaps);
   if (x_ld == 0) x_ld = cin;
   if (g_ld == 0) g_ld = cout;
-  if (x_ld < cin || g_ld < cout || (nbr && nbr_stride < rows)) return PN_EINVAL;
+  PN_CHECK_ARG(x_ld >= cin && g_ld >= cout && (!nbr || nbr_stride >= rows),
+               "pn_spconv_wgrad: row strides (%d, %d) / rulebook stride %d smaller than the data", x_ld, g_ld, nbr_stride);
   int per;
   const int chunks = wgrad_plan(rows, cin, cout, ntaps, &per);
-  if (!workspace || workspace_bytes < (size_t)chunks * ntaps * cout * cin * sizeof(float)) return PN_ENOSPC;
+  const size_t need = (size_t)chunks * ntaps * cout * cin * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    pn_set_error("pn_spconv_wgrad: workspace of %zu bytes, %zu needed (pn_spconv_wgrad_workspace_bytes)", workspace_bytes, need);
+    return PN_ENOSPC;
+  }
   WgradArgs a;
   a.x = x; a.g = grad_out; a.nbr = nbr; a.count = count_dev; a.partial = (float*)workspace;
   a.x_ld = x_ld; a.g_ld = g_ld; a.nbr_stride = nbr_stride; a.rows = rows; a.cin = cin; a.cout = cout;

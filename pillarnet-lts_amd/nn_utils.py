@@ -88,6 +88,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+SYNC_BN_COLLECTIVES = [0]      # all-reduces issued by SyncBatchNorm in this process (forward + backward), for reports
+
+
 class _SyncBNFunction(torch.autograd.Function):
     """Batch norm over the rows of ALL ranks.  Forward: one all-reduce of [sum, sum of squares,
     count] per layer; backward: one all-reduce of [sum dy, sum dy*(x-mean)].  Row counts may differ
@@ -99,6 +102,7 @@ class _SyncBNFunction(torch.autograd.Function):
         xf = x2.float()
         stats = torch.cat([xf.sum(0), (xf * xf).sum(0), xf.new_full((1,), float(x2.shape[0]))])
         dist.all_reduce(stats, group=group)
+        SYNC_BN_COLLECTIVES[0] += 1
         n = stats[2 * C]
         mean = stats[:C] / n
         var = (stats[C:2 * C] / n - mean * mean).clamp_(min=0)
@@ -117,6 +121,7 @@ class _SyncBNFunction(torch.autograd.Function):
         sums = torch.cat([dyf.sum(0), (dyf * xmu).sum(0)])
         local = sums.clone()
         dist.all_reduce(sums, group=ctx.group)
+        SYNC_BN_COLLECTIVES[0] += 1
         sum_dy, sum_dy_xmu = sums[:C], sums[C:]
         dx = (dyf - sum_dy / n - xmu * (invstd * invstd) * (sum_dy_xmu / n)) * (invstd * weight.float())
         # parameter gradients stay local sums: the gradient exchange averages them like any other

@@ -177,6 +177,21 @@ def rulebook_wgrad(feats, nbr, g, n_out):
     assert feats.dtype == torch.float32 and g.dtype == torch.float32 and feats.stride(1) == 1 and g.stride(1) == 1
     if n_out == 0:
         return torch.zeros((cout, ntaps, cin), dtype=torch.float32, device=dev)
+    if g.device.type != "cuda":
+        raise _lib.PillarnetHipError("rulebook_wgrad: tensors must live on the GPU (no CPU fallback)")
+    if cin % 32 or cout % 32:
+        # widths outside the MFMA kernel's 32-channel granularity (no live preset has one): nine gathered library
+        # GEMMs on the GPU, missing neighbours masked to zero rows instead of compacted (no host wait)
+        gw = torch.empty((cout, ntaps, cin), dtype=torch.float32, device=dev)
+        gk = g[:n_out]
+        for k in range(ntaps):
+            if nbr is None:
+                gw[:, k] = gk.t() @ feats[:n_out]
+                continue
+            idx = nbr[k, :n_out].long()
+            live = (idx >= 0).to(gk.dtype).unsqueeze(1)
+            gw[:, k] = (gk * live).t() @ feats.index_select(0, idx.clamp(min=0))
+        return gw
     L = _lib.lib()
     gw = torch.empty((cout, ntaps, cin), dtype=torch.float32, device=dev)
     ws = torch.empty(max(int(L.pn_spconv_wgrad_workspace_bytes(n_out, cin, cout, ntaps)), 1), dtype=torch.uint8, device=dev)

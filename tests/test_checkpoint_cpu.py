@@ -144,3 +144,37 @@ def test_detector_pretrained_hook(model, tmp_path, capsys):
     cfg.model.pretrained = str(tmp_path / "absent.pth")      # single_stage.py:31-38: soft failure
     presets.build(cfg)
     assert "no pretrained model at" in capsys.readouterr().out
+
+
+def test_resume_with_numpy_typed_hyper_parameters(tmp_path):
+    """an optimiser whose param_groups hold numpy scalars (a schedule that computes lr with numpy) must come back from
+    resume() with numbers, not their text; values that cannot be stored raise at save time instead of at the next step"""
+    import numpy as np
+    torch.manual_seed(1)
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt.param_groups[0]["lr"] = np.float64(2.5e-4)
+    opt.param_groups[0]["weight_decay"] = np.float32(0.5)
+    net(torch.randn(4, 3)).sum().backward()
+    opt.step()
+    f = str(tmp_path / "np.pth")
+    C.save_checkpoint(net, f, optimizer=opt, meta=dict(CLASSES=np.array([1, 2]), note=object()))
+    net2 = torch.nn.Linear(3, 2)
+    opt2 = torch.optim.Adam(net2.parameters(), lr=1.0)
+    C.resume(net2, f, optimizer=opt2)
+    g = opt2.param_groups[0]
+    assert isinstance(g["lr"], float) and g["lr"] == 2.5e-4 and isinstance(g["weight_decay"], float) and g["weight_decay"] == 0.5
+    net2(torch.randn(4, 3)).sum().backward()
+    opt2.step()                                            # the optimiser works with what came back
+    opt.param_groups[0]["hook"] = object()
+    with pytest.raises(TypeError, match="optimizer state"):
+        C.save_checkpoint(net, str(tmp_path / "bad.pth"), optimizer=opt)
+
+
+def test_bare_ordered_dict_with_a_non_tensor_entry(model, tmp_path):
+    """the reference takes any OrderedDict as a state dict (checkpoint.py:203-204)"""
+    from collections import OrderedDict
+    sd = OrderedDict(model.state_dict())
+    f = str(tmp_path / "bare.pth")
+    torch.save(OrderedDict(list(sd.items())[:4]), f)
+    P.load_checkpoint(model, f)

@@ -205,6 +205,7 @@ def test_bench_launches_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["dry_run"] is True
     assert rec["scaling"] == "weak" and rec["value"] is None
+    assert rec["ranks_seen"] == 2          # counted by an all-reduce of ones, not read from the environment
     # under an external launcher (WORLD_SIZE set) it does not spawn: one rank of a 1-rank world
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup",
                          "0", "--dry-run", "--mode", "train"], env=env, capture_output=True, text=True, timeout=300)

@@ -64,8 +64,10 @@ def test_static_nms_matches_workspace_nms_twice(cuda):
 
 def test_static_nms_rejects_sizes_beyond_the_static_array(cuda):
     L = _lib.lib()
-    S, cap = 3, 4096                          # 3 x 4096 x 64 x 8 B = 6 MiB > 2 MiB
-    assert L.pn_nms_workspace_bytes(S, cap) > (2 << 20)
+    S, cap = 3, 4096
+    bit_matrix = lambda sets, n: sets * n * ((n + 63) // 64) * 8       # the stated limit: the bit matrix alone
+    assert bit_matrix(S, cap) == 6 << 20 and bit_matrix(S, cap) > (2 << 20)
+    assert bit_matrix(1, 4096) == (2 << 20) and bit_matrix(16, 1024) == (2 << 20)   # the two largest shapes that fit
     boxes = torch.zeros((S, cap, 7), device=cuda)
     keep = torch.zeros((S, cap), dtype=torch.int32, device=cuda)
     num = torch.zeros(S, dtype=torch.int32, device=cuda)
