@@ -445,19 +445,22 @@ int pn_points_in_boxes_2d(const float* boxes, const float* pts, int batch, int b
 /* ------------------------------------------------------------------------
  * Multi-sweep merge (the data step in front of the reader).
  * Replaces the nuScenes branch of LoadPointCloudFromFile.__call__ with read_sweep / remove_close
- * (det3d/datasets/pipelines/loading.py:38-61,103-140) for sweeps already resident in HBM:
+ * (det3d/datasets/pipelines/loading.py:38-61,103-140) and its Waymo branch with read_single_waymo /
+ * read_single_waymo_sweep (:63-94,142-175) for sweeps already resident in HBM:
  *   raw [n_total, raw_dim] fp32 = the .bin files back to back (key sweep first); sweep s owns rows
  *   [sweep_start[s], sweep_start[s+1]) (HOST array of n_sweeps+1 ints).  Per sweep (device arrays):
  *   transform[s][16] float64 row-major 4x4 (used where has_transform[s]), time_lag[s] fp32,
  *   filter_close[s] (1: drop points with |x| < radius and |y| < radius, tested before the transform).
+ *   tanh_column: -1, or the feature column (3 <= c < use_dim) stored as tanhf(value) -- Waymo's intensity
+ *   normalisation (loading.py:67-68,79-80).
  * out [<= n_total, use_dim + 1] fp32: (x', y', z', raw[3..use_dim), time lag), reference row order
  * (a stable compaction); out_count: device int32.  Workspace: pn_merge_sweeps_workspace_bytes(n_total).
  * ------------------------------------------------------------------------ */
 size_t pn_merge_sweeps_workspace_bytes(int n_points);
 int pn_merge_sweeps(const float* raw, int raw_dim, int use_dim, const int32_t* sweep_start_host,
                     int n_sweeps, const double* transform, const uint8_t* has_transform,
-                    const float* time_lag, const uint8_t* filter_close, float radius, float* out,
-                    int32_t* out_count, void* workspace, size_t workspace_bytes, pnStream stream);
+                    const float* time_lag, const uint8_t* filter_close, float radius, int tanh_column,
+                    float* out, int32_t* out_count, void* workspace, size_t workspace_bytes, pnStream stream);
 
 /* ------------------------------------------------------------------------
  * Host-side hard voxelizer: the `Voxelization(cfg=voxel_generator)` pipeline step of the legacy configs,

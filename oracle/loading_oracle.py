@@ -1,9 +1,10 @@
 """CPU restatement of the reference's multi-sweep loading (numpy).  TEST INFRASTRUCTURE ONLY.
 
 Follows det3d/datasets/pipelines/loading.py:38-61 (remove_close, read_sweep) and :118-140 (the nuScenes
-branch of LoadPointCloudFromFile.__call__), on in-memory sweeps instead of .bin paths.  Pinned by
-tests/golden/loading.npz, produced by the reference's own functions on .bin files written from the same
-arrays (tests/golden/make_golden.py::golden_loading)."""
+branch of LoadPointCloudFromFile.__call__), and :63-94 (read_single_waymo, read_single_waymo_sweep) with :142-175
+(the Waymo branch), on in-memory sweeps instead of file paths.  Pinned by tests/golden/loading.npz and
+tests/golden/loading_waymo.npz, produced by the reference's own functions on files written from the same
+arrays (tests/golden/make_golden.py::golden_loading, golden_loading_waymo)."""
 import numpy as np
 
 
@@ -32,3 +33,27 @@ def combined(raw_sweeps, transforms, time_lags, num_point_feature=4):
     points = np.concatenate(pts, axis=0)
     times = np.concatenate(tms, axis=0).astype(points.dtype)
     return np.hstack([points, times])
+
+
+def waymo_frame(xyz, feat, transform=None):
+    """read_single_waymo / read_single_waymo_sweep: (xyz, tanh(intensity), elongation) [n, 5], moved by the 4x4."""
+    feat = np.array(feat, np.float32)
+    feat[:, 0] = np.tanh(feat[:, 0])
+    pts = np.concatenate([np.asarray(xyz, np.float32), feat], axis=-1).T
+    if transform is not None:
+        pts[:3, :] = np.asarray(transform).dot(np.vstack((pts[:3, :], np.ones(pts.shape[1]))))[:3, :]
+    return pts.T
+
+
+def combined_waymo(frames, transforms, time_lags):
+    """frames: list of (xyz [n, 3], feat [n, 2]), key frame first.  One frame -> points [n, 5]; several -> the
+    `combined` cloud [N, 6] (points + time lag), sweeps in the listed order, nothing filtered."""
+    pts = [waymo_frame(*frames[0])]
+    if len(frames) == 1:
+        return pts[0]
+    tms = [np.zeros((pts[0].shape[0], 1))]
+    for (xyz, feat), T, lag in zip(frames[1:], transforms[1:], time_lags[1:]):
+        pts.append(waymo_frame(xyz, feat, T))
+        tms.append(lag * np.ones((pts[-1].shape[0], 1)))
+    points = np.concatenate(pts, axis=0)
+    return np.hstack([points, np.concatenate(tms, axis=0).astype(points.dtype)])

@@ -126,7 +126,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     "pn_merge_sweeps_workspace_bytes": (c_size_t, [c_int]),
     "pn_merge_sweeps": (c_int, [c_void_p, c_int, c_int, POINTER(c_int32), c_int, c_void_p, c_void_p, c_void_p,
-                                c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

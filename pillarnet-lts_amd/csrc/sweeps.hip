@@ -1,5 +1,7 @@
 // Multi-sweep point-cloud merge on the device: the nuScenes branch of LoadPointCloudFromFile
-// (det3d/datasets/pipelines/loading.py:103-140) with read_sweep / remove_close (:38-61) --
+// (det3d/datasets/pipelines/loading.py:103-140) with read_sweep / remove_close (:38-61), and its Waymo branch
+// (:142-175 with read_single_waymo / read_single_waymo_sweep, :63-94: no close-point filter, tanh of the intensity
+// column of every sweep) --
 //   key sweep as it is (dt = 0); every other sweep: drop points with |x| < r AND |y| < r (r = 1 m, tested on
 //   the raw sensor-frame coordinates), move xyz by the sweep's 4x4 transform (float64 arithmetic, rounded
 //   to fp32 on store, as numpy's float64 dot assigned into a float32 array), append the sweep's time lag.
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(SW_T) void sweeps_write_kernel(SweepMeta M, const f
                                                             const float* __restrict__ time_lag,
                                                             const uint8_t* __restrict__ filter_close, float radius,
                                                             const int32_t* __restrict__ block_offsets,
-                                                            float* __restrict__ out) {
+                                                            int tanh_column, float* __restrict__ out) {
   __shared__ int wsum[SW_T / 64];
   const int i = blockIdx.x * SW_T + threadIdx.x, total = M.start[M.n_sweeps];
   const int s = i < total ? sweep_of(M, i) : 0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(SW_T) void sweeps_write_kernel(SweepMeta M, const f
     z = (float)(((T[8] * xd + T[9] * yd) + T[10] * zd) + T[11]);
   }
   o[0] = x; o[1] = y; o[2] = z;
-  for (int c = 3; c < use_dim; ++c) o[c] = p[c];
+  for (int c = 3; c < use_dim; ++c) o[c] = c == tanh_column ? tanhf(p[c]) : p[c];
   o[use_dim] = time_lag[s];
 }
 
@@ -109,12 +111,14 @@ extern "C" size_t pn_merge_sweeps_workspace_bytes(int n_points) {
 
 extern "C" int pn_merge_sweeps(const float* raw, int raw_dim, int use_dim, const int32_t* sweep_start_host,
                                int n_sweeps, const double* transform, const uint8_t* has_transform,
-                               const float* time_lag, const uint8_t* filter_close, float radius, float* out,
-                               int32_t* out_count, void* workspace, size_t workspace_bytes, pnStream stream_) {
+                               const float* time_lag, const uint8_t* filter_close, float radius, int tanh_column,
+                               float* out, int32_t* out_count, void* workspace, size_t workspace_bytes, pnStream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(sweep_start_host && out_count && n_sweeps >= 1 && n_sweeps <= SW_MAX,
                "pn_merge_sweeps: 1..%d sweeps", SW_MAX);
   PN_CHECK_ARG(raw_dim >= 3 && use_dim >= 3 && use_dim <= raw_dim, "pn_merge_sweeps: bad point layout");
+  PN_CHECK_ARG(tanh_column < 0 || (tanh_column >= 3 && tanh_column < use_dim),
+               "pn_merge_sweeps: tanh_column %d is not a feature column (3..%d) or -1", tanh_column, use_dim - 1);
   SweepMeta M;
   M.n_sweeps = n_sweeps;
   for (int s = 0; s <= n_sweeps; ++s) {
@@ -140,7 +144,7 @@ extern "C" int pn_merge_sweeps(const float* raw, int raw_dim, int use_dim, const
   hipLaunchKernelGGL(sweeps_scan_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nblocks, out_count);
   PN_CHECK_LAUNCH("sweeps_scan_kernel");
   hipLaunchKernelGGL(sweeps_write_kernel, dim3(nblocks), dim3(SW_T), 0, stream, M, raw, raw_dim, use_dim, transform,
-                     has_transform, time_lag, filter_close, radius, block_sums, out);
+                     has_transform, time_lag, filter_close, radius, block_sums, tanh_column, out);
   PN_CHECK_LAUNCH("sweeps_write_kernel");
   return PN_OK;
 }

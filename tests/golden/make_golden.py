@@ -13,7 +13,7 @@ Reference code executed here (imported from /root/reference, nothing copied):
   det3d/ops/iou3d_nms/src/iou3d_cpu.cpp (compiled, oracle/_ref)      -> iou3d.npz
   det3d.models.second_stage.BEVStrideFeature, roi_heads.RoIMIXHead, point_heads.PointHead,
   detectors.pillar_rcnn.PillarRCNN.post_process       -> rcnn.npz
-  det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz
+  det3d.datasets.pipelines.loading.LoadPointCloudFromFile / read_sweep -> loading.npz (nuScenes), loading_waymo.npz (Waymo)
   roi_heads ProposalTargetLayer / RoIHeadTemplate.assign_targets + get_loss, PointHead targets + loss -> rcnn_train.npz
   second_stage BEVFeature, roi_heads RoIFFNHead (without mmcv's FFN block) / RoIHead training -> rcnn_extra.npz
   det3d.ops.point_cloud.point_cloud_ops.points_to_voxel (interpreted)  -> voxelize.npz
@@ -828,6 +828,48 @@ def golden_loading():
     save("loading.npz", **arrays)
 
 
+def golden_loading_waymo():
+    """LoadPointCloudFromFile (WaymoDataset branch) / read_single_waymo(_sweep) of the reference on frame pickles written
+    to a temporary directory in the layout its converter produces ({"lidars": {"points_xyz", "points_feature"}}): one
+    sweep (points only) and three sweeps (combined)."""
+    import pickle
+    import tempfile
+    for pkg in ("det3d.datasets", "det3d.datasets.pipelines"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules.setdefault(pkg, m)
+    from det3d.datasets.pipelines.loading import LoadPointCloudFromFile
+    rs = np.random.RandomState(27)
+    arrays = {}
+    with tempfile.TemporaryDirectory() as d:
+        paths, sweeps = [], []
+        for i in range(3):
+            n = int(rs.randint(1800, 2600))
+            xyz = (rs.randn(n, 3) * [25.0, 25.0, 1.5]).astype(np.float32)
+            xyz[: n // 10, :2] = rs.uniform(-0.8, 0.8, (n // 10, 2))       # points near the sensor stay (no close filter)
+            feat = np.stack([np.exp(rs.randn(n) * 1.5), rs.rand(n) * 1.5], axis=1).astype(np.float32)   # intensity, elongation
+            arrays[f"xyz.{i}"], arrays[f"feat.{i}"] = xyz.copy(), feat.copy()
+            path = os.path.join(d, f"frame{i}.pkl")
+            with open(path, "wb") as f:
+                pickle.dump({"lidars": {"points_xyz": xyz, "points_feature": feat}}, f)
+            paths.append(path)
+            if i:
+                ang = rs.uniform(-0.1, 0.1)
+                T = np.eye(4)
+                T[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+                T[:3, 3] = rs.randn(3) * [1.5, 0.3, 0.02]
+                sweeps.append({"path": path, "transform_matrix": T if i != 2 else None, "time_lag": float(0.1 * i)})
+                arrays[f"transform.{i}"] = np.full((4, 4), np.nan) if i == 2 else T
+                arrays[f"time_lag.{i}"] = np.asarray(sweeps[-1]["time_lag"])
+        one, _ = LoadPointCloudFromFile(dataset="WaymoDataset")({"lidar": {"nsweeps": 1}}, {"path": paths[0]})
+        three, _ = LoadPointCloudFromFile(dataset="WaymoDataset")({"lidar": {"nsweeps": 3}}, {"path": paths[0], "sweeps": sweeps})
+    arrays["one.points"] = one["lidar"]["points"]
+    assert "combined" not in one["lidar"]
+    arrays["three.points"], arrays["three.times"] = three["lidar"]["points"], three["lidar"]["times"]
+    arrays["three.combined"] = three["lidar"]["combined"]
+    save("loading_waymo.npz", **arrays)
+
+
 def collate_batch():
     """A seeded two-sample batch with every key family collate_kitti distinguishes (one sample given as a list of
     sub-examples, as the double-flip pipeline produces)."""
@@ -917,5 +959,6 @@ if __name__ == "__main__":
     golden_train(head)
     golden_rcnn()
     golden_loading()
+    golden_loading_waymo()
     golden_rcnn_train()
     golden_rcnn_extra()

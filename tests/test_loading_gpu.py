@@ -86,3 +86,71 @@ def test_merge_rejects_host_output():
     from pillarnet_lts_amd._lib import PillarnetHipError
     with pytest.raises(PillarnetHipError):
         loading.merge_sweeps([np.zeros((3, 5), np.float32)], [None], [0.0], "cpu")
+
+
+# ---- Waymo branch (loading.py:63-100,142-175) ------------------------------------------------------------------
+def _waymo_golden():
+    g = np.load(os.path.join(G, "loading_waymo.npz"))
+    frames = [(g[f"xyz.{i}"], g[f"feat.{i}"]) for i in range(3)]
+    mats = [None, g["transform.1"], None]                 # the third frame carries no transform (nan block in the fixture)
+    assert np.isnan(g["transform.2"]).all()
+    lags = [0.0, float(g["time_lag.1"]), float(g["time_lag.2"])]
+    return g, frames, mats, lags
+
+
+def _close_waymo(got, want):
+    """elongation / time lag / untransformed xyz exact; transformed xyz to one fp32 ulp (as the nuScenes branch);
+    tanh(intensity): device tanhf against numpy's, 2 ulp of a value below 1 (2.4e-7)."""
+    assert got.shape == want.shape and got.dtype == np.float32
+    np.testing.assert_array_equal(got[:, 4:], want[:, 4:])
+    np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=1.2e-7, atol=1e-6)
+    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=0, atol=2.4e-7)
+
+
+def test_waymo_pipeline_matches_reference_output(cuda, tmp_path):
+    """LoadPointCloudFromFile(dataset="WaymoDataset") on frame pickles this test writes (the converter's layout) against
+    what the reference's own class returned for the same arrays (tests/golden/loading_waymo.npz): one sweep -> `points`
+    only; three sweeps in the listed order -> `combined`, nothing filtered, intensity through tanh."""
+    import pickle
+    g, frames, mats, lags = _waymo_golden()
+    paths = []
+    for i, (xyz, feat) in enumerate(frames):
+        p = tmp_path / f"frame{i}.pkl"
+        with open(p, "wb") as f:
+            pickle.dump({"lidars": {"points_xyz": xyz.copy(), "points_feature": feat.copy()}}, f)
+        paths.append(str(p))
+    step = loading.LoadPointCloudFromFile(dataset="WaymoDataset", device=cuda)
+    one, _ = step({"lidar": {"nsweeps": 1}}, {"path": paths[0]})
+    assert one["type"] == "WaymoDataset" and "combined" not in one["lidar"] and one["lidar"]["points"].is_cuda
+    _close_waymo(one["lidar"]["points"].cpu().numpy(), g["one.points"])
+    sweeps = [{"path": paths[i], "transform_matrix": mats[i], "time_lag": lags[i]} for i in (1, 2)]
+    three, _ = step({"lidar": {"nsweeps": 3}}, {"path": paths[0], "sweeps": sweeps})
+    _close_waymo(three["lidar"]["combined"].cpu().numpy(), g["three.combined"])
+    np.testing.assert_array_equal(three["lidar"]["times"].cpu().numpy(), g["three.times"])
+    assert three["lidar"]["points"].shape == g["three.points"].shape
+    n0 = frames[0][0].shape[0]
+    assert three["lidar"]["combined"].shape[0] == sum(f[0].shape[0] for f in frames)          # no close-point filter
+    np.testing.assert_array_equal(three["lidar"]["combined"][:n0, :3].cpu().numpy(), frames[0][0])
+    with pytest.raises(AssertionError):
+        step({"lidar": {"nsweeps": 2}}, {"path": paths[0], "sweeps": sweeps})
+    with pytest.raises(NotImplementedError):
+        loading.LoadPointCloudFromFile(dataset="KittiDataset", device=cuda)({"lidar": {"nsweeps": 1}}, {})
+
+
+def test_waymo_merge_full_size_vs_oracle(cuda):
+    """configs[2]-sized frame (180 000 points) + two earlier sweeps against the numpy oracle"""
+    rs = np.random.RandomState(4)
+    frames, mats, lags = [], [], []
+    for i in range(3):
+        n = 180000 - 777 * i
+        frames.append(((rs.randn(n, 3) * [40.0, 40.0, 2.0]).astype(np.float32),
+                       np.stack([np.exp(rs.randn(n) * 2), rs.rand(n)], 1).astype(np.float32)))
+        T = np.eye(4)
+        T[:3, :3] += rs.randn(3, 3) * 0.01
+        T[:3, 3] = rs.randn(3)
+        mats.append(None if i == 0 else T)
+        lags.append(0.1 * i)
+    want = lo.combined_waymo(frames, mats, lags)
+    raws = [np.concatenate(f, axis=1) for f in frames]
+    got = loading.merge_sweeps(raws, mats, lags, cuda, num_point_feature=5, filter_close=[0, 0, 0], tanh_column=3)
+    _close_waymo(got.cpu().numpy(), want)

@@ -173,6 +173,19 @@ def test_rcnn_second_stage_restatement_matches_reference():
     assert len(dets[1]["scores"]) == R - 3       # the padded proposals are dropped
 
 
+def test_waymo_loading_restatement_matches_reference():
+    """oracle/loading_oracle.combined_waymo vs the reference's LoadPointCloudFromFile (WaymoDataset branch) on the same
+    frames (tests/golden/loading_waymo.npz): bit-exact, one sweep and three."""
+    from oracle import loading_oracle as lo
+    g = load("loading_waymo.npz")
+    frames = [(g[f"xyz.{i}"], g[f"feat.{i}"]) for i in range(3)]
+    mats, lags = [None, g["transform.1"], None], [0.0, float(g["time_lag.1"]), float(g["time_lag.2"])]
+    np.testing.assert_array_equal(lo.combined_waymo(frames[:1], [None], [0.0]), g["one.points"])
+    got = lo.combined_waymo(frames, mats, lags)
+    assert got.dtype == np.float32 and got.shape[0] == sum(f[0].shape[0] for f in frames)
+    np.testing.assert_array_equal(got, g["three.combined"])
+
+
 def test_loading_restatement_matches_reference():
     """oracle/loading_oracle.py vs the reference's LoadPointCloudFromFile on the same sweeps (bit-exact: same
     numpy expressions)."""
