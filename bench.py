@@ -525,6 +525,36 @@ def run_train(args):
     early = (trainer.buckets.launched_early - early0) / max(args.steps, 1) if trainer.buckets is not None else 0
     bn_coll = (nn_utils.SYNC_BN_COLLECTIVES[0] - bn0) / max(args.steps, 1)
 
+    # matrix work of the step, counted on the live rulebooks of one sample: every convolution (sparse levels, conv5,
+    # neck, the DENSE head -- training evaluates every tower at every cell) once forward, once for the data gradient,
+    # once for the weight gradient; against the fp32 matrix peak (v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s)
+    step_flops = None
+    if rank == 0:
+        try:
+            import copy
+            from pillarnet_lts_amd import _lib
+            probe = copy.deepcopy(model).to_inference(torch.bfloat16)
+            with torch.no_grad():
+                _lib.FLOP_LOG = []
+                bev, _ = probe.extract_feat(dict(points=[ex["points"][0]], batch_size=1))
+                conv = sum(per_pair * float(pairs) for _, per_pair, pairs in _lib.FLOP_LOG)
+                _lib.FLOP_LOG = None
+            head = 0.0
+            for f, sc in zip(bev, probe.bbox_head.share_convs):
+                cells = f.shape[2] * f.shape[3]
+                head += 2.0 * 9 * sc[0].in_channels * sc[0].out_channels * cells
+            for t, th in enumerate(probe.bbox_head.task_heads):
+                f = bev[probe.bbox_head.task_idx[t]]
+                cells = f.shape[2] * f.shape[3]
+                for m in th.modules():
+                    if isinstance(m, torch.nn.Conv2d):
+                        head += 2.0 * 9 * m.in_channels * m.out_channels * cells
+            step_flops = 3.0 * (conv + head) * per_gpu
+            del probe
+        except Exception as e:      # the accounting must never cost the measurement
+            print(f"bench.py: flop accounting skipped ({e})", file=sys.stderr)
+            _lib.FLOP_LOG = None
+
     # the gradient exchange alone: one flat all-reduce of the same byte count, bus bandwidth per the
     # ring formula 2 (N-1)/N * bytes / t against one xGMI link (~153 GB/s)
     n_param = sum(p.numel() for p in model.parameters() if p.requires_grad)
@@ -555,6 +585,8 @@ def run_train(args):
                        "parallelism": f"dp{world}", "sync_bn": trainer.sync_bn, "overlap": trainer.overlap,
                        "loss_last_step": round(float(loss), 4),
                        "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
+            "step_flops_per_gpu": None if step_flops is None else round(step_flops),
+            "fp32_matrix_frac": None if step_flops is None else round(step_flops / (elapsed / args.steps) / 157.3e12, 4),
             "ranks_seen": ranks_seen,
             "per_rank_samples_per_s": {"min": round(rank_sps[0], 3), "max": round(rank_sps[1], 3)},
             "gradient_buckets": {"count": n_buckets, "launched_early_per_step": round(early, 2),
