@@ -372,7 +372,8 @@ def run_infer(args):
         roof = roof_one = None
         shared = (not args.no_graph) and getattr(runner, "shared_cu_tiles", False)
         if shared and len(runner.lanes) > 1:
-            got = probe_conv(1, runner.lanes[1])
+            alone = probe_conv(1, None)          # the same launches with the other lane idle: what a kernel trace, which
+            got = probe_conv(1, runner.lanes[1])  # serialises the streams, reports for this kernel
             if got:
                 avg_ms, n, pairs, rows, cap = got
                 ach = 2.0 * cin * cout * pairs / (avg_ms * 1e-3) / 1e12
@@ -383,6 +384,7 @@ def run_infer(args):
                                   f"tiles, sparse SubM {cin}->{cout}; the kernel the timed graphs run for the 256-wide layers)",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": pmc_traffic(f"spconv_{cin}x{cout}_fused", "r03_pmc_traffic.json"), "launches": n, "avg_us": round(avg_ms * 1e3, 2),
+                        "avg_us_other_lane_idle": round(alone[0] * 1e3, 2) if alone else None,
                         "active_pairs": pairs, "rows": rows, "workgroups": tiles, "cus_used": cus,
                         "frac_of_occupied_cus": round(ach / (peak * cus / 256.0), 4),
                         "measured": "HIP events around the launches of eager frames under the graphs' tile policy while "
