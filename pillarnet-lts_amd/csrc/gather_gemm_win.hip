@@ -891,7 +891,15 @@ static int launch_win(const GGArgs& a, int groups, hipStream_t stream) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_set = true;
   }
-  const dim3 grid(pn_div_up(a.rows, BM), pn_div_up(a.cout_total, BN), groups);
+  // Workgroups go round robin over the eight XCDs by their linear id (x fastest).  With several column tiles or groups
+  // the row dimension is padded to a multiple of eight (the extra workgroups exit at once), so that the column tiles
+  // of one row tile -- which read the same window -- run on the same XCD and share its L2.
+  int gx = pn_div_up(a.rows, BM);
+  const int gy = pn_div_up(a.cout_total, BN);
+#ifndef GGW_NO_XCD_PAD
+  if (gy * groups > 1) gx = (gx + 7) & ~7;
+#endif
+  const dim3 grid(gx, gy, groups);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, stream, a, force_gather);
   PN_CHECK_LAUNCH("gg_win_kernel");
   return PN_OK;
