@@ -31,8 +31,9 @@ __global__ __launch_bounds__(NWAVES * 64) void probe(int iters, float* sink, uns
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[i])::"memory");
   float s = 0;
-  for (int i = 0; i < 8; ++i) s += acc[i][0];
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + (float)f[i][0];
   if (s == 12345.f) sink[0] = s + v0;
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(NWAVES * 64) void kstep(int iters, float* sink, uns
   unsigned addr = base + (unsigned)(((lane & 31) * 128) + ((((lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
   for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(f[0][i]) : "v"(addr + i * 4096));
   for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(f[1][i]) : "v"(addr + i * 4096));
+  for (int b = 0; b < 2; ++b)     // the results are operands of the wait: their registers stay theirs until the loads landed
+    for (int i = 0; i < 4; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[b][i])::"memory");
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -90,8 +93,11 @@ __global__ __launch_bounds__(NWAVES * 64) void kstep(int iters, float* sink, uns
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < 4; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[b][i])::"memory");
   float s = 0;
   for (int i = 0; i < G; ++i) s += acc[i][0];
+  for (int b = 0; b < 2; ++b) for (int i = 0; i < 4; ++i) s += (float)f[b][i][0];
   if (s == 12345.f) sink[0] = s;
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
@@ -137,6 +143,8 @@ __global__ __launch_bounds__(NWAVES * 64) void kstep16(int iters, float* sink, u
   unsigned addr = base + (unsigned)(((lane & 15) * 128) + ((((lane >> 4)) ^ ((lane >> 1) & 7)) << 4));
   for (int b = 0; b < 2; ++b)
     for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(f[b][i]) : "v"(addr + i * 2048));
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[b][i])::"memory");
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -151,8 +159,11 @@ __global__ __launch_bounds__(NWAVES * 64) void kstep16(int iters, float* sink, u
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[b][i])::"memory");
   float s = 0;
   for (int i = 0; i < 16; ++i) s += acc[i][0];
+  for (int b = 0; b < 2; ++b) for (int i = 0; i < 8; ++i) s += (float)f[b][i][0];
   if (s == 12345.f) sink[0] = s;
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
@@ -174,9 +185,240 @@ void runk16(float* sink, unsigned long long* cyc) {
          RANDOM ? " (random operands)" : "", NWAVES, R, (double)c / n, c / (ms * 1e6), 256.0 * NWAVES * n * 16384.0 / (ms * 1e-3) / 1e12);
 }
 
-int main() {
+// Weights straight from L2 into registers: per k-step TM ds_read_b128 (activation fragments) + TN global 1-KB fragment
+// loads (pre-packed weight fragments, D k-steps ahead) + TM*TN MFMAs.  Waves with the same wave % 4 read the same weights.
+template <int NWAVES, int TM, int TN, int D>
+__global__ __launch_bounds__(NWAVES * 64) void kstep_regb(int iters, const char* w, float* sink, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3;
+  for (int i = tid; i < 16384; i += NWAVES * 64) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned lo = (h & 0x807fu) | 0x3b80u, hi = ((h >> 16) & 0x807fu) | 0x3b80u;
+    reinterpret_cast<unsigned*>(smem)[i] = lo | (hi << 16);
+  }
+  __syncthreads();
+  constexpr int G = TM * TN, RB = D + 1, NBLK = 4 * TN;      // 1-KB blocks per k-step over the 4 column waves
+  f32x16 acc[G];
+  for (int i = 0; i < G; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 fa[2][TM], fb[RB][TN];
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned addr = base + (unsigned)(((lane & 31) * 128) + ((((lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+  // An asm load whose result is never used leaves its registers free for the compiler while the load is still in
+  // flight (it then lands on whatever was put there, an address for instance): every load below is either consumed
+  // behind a wait or named as an operand of the wait that retires it.
+  for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][i]) : "v"(addr + i * 4096));
+  for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][i])::"memory");
+  const unsigned voff = (unsigned)(wn * TN * 1024 + lane * 16);
+  const unsigned KSTEPS = 144;                                // 9 taps x 256 channels / 16
+  unsigned q = 0;                                             // k-step whose weights are requested next
+  for (int d = 0; d < D; ++d) {
+    const char* p = w + (size_t)q * NBLK * 1024;
+    for (int j = 0; j < TN; ++j) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(fb[d][j]) : "v"(voff), "s"(p), "n"(0));
+    q = q + 1 == KSTEPS ? 0 : q + 1;
+  }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2 * RB; ++u) {
+      const char* p = w + (size_t)q * NBLK * 1024;
+      q = q + 1 == KSTEPS ? 0 : q + 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fb[(u + D) % RB][j]) : "v"(voff + j * 1024), "s"(p));
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * TN) : "memory");
+#pragma unroll
+      for (int r = 0; r < TM; ++r)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[(u + 1) & 1][r]) : "v"(addr + ((it + r) & 7) * 4096));
+#pragma unroll
+      for (int m = 0; m < G; ++m)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(fb[u % RB][m % TN]), "v"(fa[u & 1][m / TN]));
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int d = 0; d < RB; ++d)
+    for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fb[d][j])::"memory");
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fa[b][i])::"memory");
+  float s = 0;
+  for (int i = 0; i < G; ++i) s += acc[i][0];
+  for (int d = 0; d < RB; ++d) for (int j = 0; j < TN; ++j) s += (float)fb[d][j][0];
+  for (int b = 0; b < 2; ++b) for (int i = 0; i < TM; ++i) s += (float)fa[b][i][0];
+  if (s == 12345.f) sink[0] = s;
+  if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
+}
+template <int NWAVES, int TM, int TN, int D>
+void runb(const char* w, float* sink, unsigned long long* cyc) {
+  const int iters = 500;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  hipFuncSetAttribute((const void*)kstep_regb<NWAVES, TM, TN, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kstep_regb<NWAVES, TM, TN, D>), dim3(256), dim3(NWAVES * 64), 65536, 0, iters, w, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double n = iters * 2.0 * (D + 1) * TM * TN;
+  printf("regB: waves/CU %2d  %d MFMA + %d ds_read_b128 + %d global 1-KB loads (%d k-steps ahead) per k-step : %5.1f ticks/MFMA/wave  (%.0f TF/s chip)\n",
+         NWAVES, TM * TN, TM, TN, D, (double)c / n, 256.0 * NWAVES * n * 32768.0 / (ms * 1e-3) / 1e12);
+}
+
+// The fused 256 x 256 tile's traffic in one loop, 8 waves, 12 k-steps (three stages) per period:
+// MODE 0 -- weights through LDS: 8 MFMA + 6 ds_read_b128 per k-step; waves 0-3 send 8 weight pieces (1-KB LDS-DMA) at the top
+//           of each stage and 9 window pieces at the top of the first; vmcnt wait + barrier at the end of every stage.
+// MODE 1 -- weights from L2 into registers: 8 MFMA + 4 ds_read_b128 + 2 global 1-KB loads (3 k-steps ahead) per k-step;
+//           waves 0-3 send one window piece in each of the first nine k-steps; one barrier per period.
+template <int MODE>
+__global__ __launch_bounds__(512) void kmix(int iters, const char* w, unsigned wbytes, float* sink, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave & 3;
+  const bool stager = wave < 4;
+  for (int i = tid; i < 8192; i += 512) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    reinterpret_cast<unsigned*>(smem)[i] = (h & 0x807fu) | 0x3b80u | ((((h >> 16) & 0x807fu) | 0x3b80u) << 16);
+  }
+  __syncthreads();
+  constexpr int TM = 4, TN = 2, G = 8, D = 3, RB = D + 1, U = 12;
+  f32x16 acc[G];
+  for (int i = 0; i < G; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 fa[2][TM], fb[RB][TN];
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned addr = base + (unsigned)(((lane & 31) * 128) + ((((lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+  auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)wbytes, 0x00020000);
+  unsigned dsrc = (unsigned)(wave * 9 * 1024 + lane * 16);   // DMA source cursor (wraps inside the 2 MB buffer)
+  unsigned ddst = 0;                                         // DMA destination piece inside [32 KB, 96 KB)
+#define DMA_PIECE()                                                                                    \
+  do {                                                                                                 \
+    auto lds_ = (__attribute__((address_space(3))) void*)(smem + 32768 + ((ddst + wave) & 63) * 1024);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_, 16, dsrc, 0, 0, 0);                             \
+    dsrc = (dsrc + 36 * 1024) & (1u << 20) - 1;                                                        \
+    ddst += 4;                                                                                         \
+  } while (0)
+  for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][i]) : "v"(addr + i * 4096));
+  for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][i])::"memory");
+  if (MODE == 0) {
+    for (int j = 0; j < TN; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0][j]) : "v"(addr + 16384 + j * 4096));
+    for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][j])::"memory");
+  }
+  const unsigned voff = (unsigned)(wn * TN * 1024 + lane * 16);
+  unsigned q = 0;
+  if (MODE == 1) {
+    for (int d = 0; d < D; ++d) {
+      const char* p = w + (size_t)q * 8 * 1024;
+      for (int j = 0; j < TN; ++j) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fb[d][j]) : "v"(voff + j * 1024), "s"(p));
+      q = q + 1 == 144 ? 0 : q + 1;
+    }
+  }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (MODE == 0) {
+        if (u % 4 == 0 && stager) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) DMA_PIECE();
+          if (u == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) DMA_PIECE();
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < G; ++m) {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(fb[u & 1][m % TN]), "v"(fa[u & 1][m / TN]));
+          if (m < 3) {
+#pragma unroll
+            for (int r = 2 * m; r < 2 * m + 2; ++r) {
+              if (r < TM) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[(u + 1) & 1][r]) : "v"(addr + ((it + r) & 3) * 4096));
+              else asm volatile("ds_read_b128 %0, %1" : "=v"(fb[(u + 1) & 1][r - TM]) : "v"(addr + 16384 + ((it + r) & 3) * 4096));
+            }
+          }
+        }
+        if (u % 4 == 3) {
+          if (u == 3) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      } else {
+        if (u < 9 && stager) DMA_PIECE();
+        const char* p = w + (size_t)q * 8 * 1024;
+        q = q + 1 == 144 ? 0 : q + 1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fb[(u + D) % RB][j]) : "v"(voff + j * 1024), "s"(p));
+        // loads issued behind the weights of this k-step: those of the last D k-steps, and the stagers' pieces among them
+        int np = 0;
+#pragma unroll
+        for (int v = u - D + 1; v <= u; ++v) np += ((v + U) % U) < 9 ? 1 : 0;
+        if (stager) {
+          if (np == 3) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+          else if (np == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          else if (np == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        }
+        if (u == U - 1) __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < G; ++m) {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(fb[u % RB][m % TN]), "v"(fa[u & 1][m / TN]));
+          if (m < 2) {
+#pragma unroll
+            for (int r = 2 * m; r < 2 * m + 2; ++r)
+              asm volatile("ds_read_b128 %0, %1" : "=v"(fa[(u + 1) & 1][r]) : "v"(addr + ((it + r) & 7) * 4096));
+          }
+        }
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int d = 0; d < RB; ++d)
+    for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fb[d][j])::"memory");
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fa[b][i])::"memory");
+  float s = 0;
+  for (int i = 0; i < G; ++i) s += acc[i][0];
+  for (int d = 0; d < RB; ++d) for (int j = 0; j < TN; ++j) s += (float)fb[d][j][0];
+  for (int b = 0; b < 2; ++b) for (int i = 0; i < TM; ++i) s += (float)fa[b][i][0];
+  __syncthreads();
+  if (s == 12345.f) sink[0] = s + smem[40000 + tid];
+  if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
+}
+template <int MODE>
+void runmix(const char* w, float* sink, unsigned long long* cyc, int blocks) {
+  const int iters = 200;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  hipFuncSetAttribute((const void*)kmix<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kmix<MODE>), dim3(blocks), dim3(512), 98304, 0, iters, w, 2u << 20, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double n = iters * 12.0 * 8;
+  printf("mix %s, %d workgroups: %.0f TF/s per 256 CUs (%.1f ticks/MFMA/wave)\n",
+         MODE ? "weights L2 -> registers, window pieces by DMA" : "weights + window by DMA through LDS", blocks,
+         256.0 * 8 * n * 32768.0 / (ms * 1e-3) / 1e12, (double)c / n);
+}
+
+int main(int argc, char**) {
   float* sink; unsigned long long* cyc;
   hipMalloc(&sink, 4); hipMalloc(&cyc, 8);
+  char* wbuf; hipMalloc(&wbuf, 144 * 16 * 1024 + 65536); hipMemset(wbuf, 0x3b, 144 * 16 * 1024 + 65536);
+  for (int i = 0; i < 40; ++i)        // the clock takes a while to come up on a cold card
+    hipLaunchKernelGGL((kstep<8, 8, 0, 1>), dim3(256), dim3(512), 65536, 0, 2000, sink, cyc);
+  hipDeviceSynchronize();
+  for (int rep = 0; rep < 3; ++rep) {
+    runmix<0>(wbuf, sink, cyc, 256); runmix<1>(wbuf, sink, cyc, 256); runmix<0>(wbuf, sink, cyc, 127); runmix<1>(wbuf, sink, cyc, 127);
+    runk<8, 8, 6, 1>(sink, cyc);
+    runb<8, 4, 2, 2>(wbuf, sink, cyc); runb<8, 4, 2, 3>(wbuf, sink, cyc); runb<8, 4, 2, 5>(wbuf, sink, cyc);
+    runb<8, 2, 4, 3>(wbuf, sink, cyc); runb<4, 4, 2, 3>(wbuf, sink, cyc); runb<8, 2, 2, 3>(wbuf, sink, cyc);
+  }
+  if (argc < 2) return 0;      // any argument: the older sweeps too
   hipFuncSetAttribute((const void*)probe<4, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   run<4, 0, 0>(sink, cyc); run<4, 2, 0>(sink, cyc); run<4, 4, 0>(sink, cyc); run<4, 6, 0>(sink, cyc); run<4, 8, 0>(sink, cyc);
   run<4, 0, 8>(sink, cyc); run<4, 0, 16>(sink, cyc); run<4, 0, 32>(sink, cyc);
