@@ -669,7 +669,12 @@ __global__ __launch_bounds__((NWM * NWN + NWL) * 64) void gg_win_kernel(GGArgs a
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 1);
         GGW_STAMP(wave == 0 && s < GGW_STAMP_STAGES, 4 + s * 4 + 2);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued behind the last k-step (unused) have landed
+      // the reads issued behind the last k-step (unused) have landed.  Their registers are operands of the wait: a
+      // result nobody uses would otherwise leave them free for the compiler while the loads are still in flight
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][i])::"memory");
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[0][j])::"memory");
     }
   }
   } else {
