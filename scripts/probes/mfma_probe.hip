@@ -405,6 +405,95 @@ void runmix(const char* w, float* sink, unsigned long long* cyc, int blocks) {
          256.0 * 8 * n * 32768.0 / (ms * 1e-3) / 1e12, (double)c / n);
 }
 
+// The same traffic on FOUR waves of 128 x 128 (one per SIMD, accumulators in AGPRs): 16 MFMA + 8 ds_read_b128 per k-step and
+// wave, every wave sends 8 weight pieces per stage and 9 window pieces per three stages.  Half the LDS reads per MFMA of the
+// 8-wave tile, but nothing else runs on a SIMD while its one wave issues DMA or waits.
+__global__ __launch_bounds__(256) void kmix4(int iters, const char* w, unsigned wbytes, float* sink, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 8192; i += 256) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    reinterpret_cast<unsigned*>(smem)[i] = (h & 0x807fu) | 0x3b80u | ((((h >> 16) & 0x807fu) | 0x3b80u) << 16);
+  }
+  __syncthreads();
+  constexpr int TM = 4, TN = 4, G = 16, U = 12;
+  f32x16 acc[G];
+  for (int i = 0; i < G; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int i = 0; i < G; ++i) asm volatile("" : "+a"(acc[i]));
+  bf16x8 fa[2][TM], fb[2][TN];
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned addr = base + (unsigned)(((lane & 31) * 128) + ((((lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+  auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)wbytes, 0x00020000);
+  unsigned dsrc = (unsigned)(wave * 9 * 1024 + lane * 16);
+  unsigned ddst = 0;
+#define DMA_PIECE4()                                                                                   \
+  do {                                                                                                 \
+    auto lds_ = (__attribute__((address_space(3))) void*)(smem + 32768 + ((ddst + wave) & 63) * 1024);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_, 16, dsrc, 0, 0, 0);                             \
+    dsrc = (dsrc + 36 * 1024) & (1u << 20) - 1;                                                        \
+    ddst += 4;                                                                                         \
+  } while (0)
+  for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][i]) : "v"(addr + i * 4096));
+  for (int j = 0; j < TN; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0][j]) : "v"(addr + 16384 + j * 4096));
+  for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][i])::"memory");
+  for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][j])::"memory");
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int m = 0; m < G; ++m) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(fb[u & 1][m % TN]), "v"(fa[u & 1][m / TN]));
+        if (m < 4) {
+#pragma unroll
+          for (int r = 2 * m; r < 2 * m + 2; ++r) {
+            if (r < TM) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[(u + 1) & 1][r]) : "v"(addr + ((it + r) & 3) * 4096));
+            else asm volatile("ds_read_b128 %0, %1" : "=v"(fb[(u + 1) & 1][r - TM]) : "v"(addr + 16384 + ((it + r) & 3) * 4096));
+          }
+        }
+        // the stage's DMA pieces go out one per MFMA behind the fragment reads (the wave is the SIMD's only one: a burst in
+        // front of the MFMAs would idle the pipe for its whole issue time)
+        if (u % 4 == 0 && m >= 4 && m < 12) DMA_PIECE4();
+        if (u == 1 && m >= 4 && m < 13) DMA_PIECE4();
+      }
+      if (u % 4 == 3) {
+        if (u == 3) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int b = 0; b < 2; ++b) {
+    for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fa[b][i])::"memory");
+    for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fb[b][j])::"memory");
+  }
+  float s = 0;
+  for (int i = 0; i < G; ++i) s += acc[i][0];
+  for (int b = 0; b < 2; ++b) for (int i = 0; i < TM; ++i) s += (float)fa[b][i][0] + (float)fb[b][i][0];
+  __syncthreads();
+  if (s == 12345.f) sink[0] = s + smem[40000 + tid];
+  if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
+}
+void runmix4(const char* w, float* sink, unsigned long long* cyc, int blocks) {
+  const int iters = 200;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  hipFuncSetAttribute((const void*)kmix4, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kmix4, dim3(blocks), dim3(256), 98304, 0, iters, w, 2u << 20, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double n = iters * 12.0 * 16;
+  printf("mix 4 waves of 128 x 128 (AGPR accumulators), weights + window by DMA through LDS, %d workgroups: %.0f TF/s per 256 CUs (%.1f ticks/MFMA/wave)\n",
+         blocks, 256.0 * 4 * n * 32768.0 / (ms * 1e-3) / 1e12, (double)c / n);
+}
+
 int main(int argc, char**) {
   float* sink; unsigned long long* cyc;
   hipMalloc(&sink, 4); hipMalloc(&cyc, 8);
@@ -413,6 +502,7 @@ int main(int argc, char**) {
     hipLaunchKernelGGL((kstep<8, 8, 0, 1>), dim3(256), dim3(512), 65536, 0, 2000, sink, cyc);
   hipDeviceSynchronize();
   for (int rep = 0; rep < 3; ++rep) {
+    runmix4(wbuf, sink, cyc, 256); runmix4(wbuf, sink, cyc, 127);
     runmix<0>(wbuf, sink, cyc, 256); runmix<1>(wbuf, sink, cyc, 256); runmix<0>(wbuf, sink, cyc, 127); runmix<1>(wbuf, sink, cyc, 127);
     runk<8, 8, 6, 1>(sink, cyc);
     runb<8, 4, 2, 2>(wbuf, sink, cyc); runb<8, 4, 2, 3>(wbuf, sink, cyc); runb<8, 4, 2, 5>(wbuf, sink, cyc);
