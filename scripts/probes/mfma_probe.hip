@@ -269,7 +269,7 @@ void runb(const char* w, float* sink, unsigned long long* cyc) {
 //           of each stage and 9 window pieces at the top of the first; vmcnt wait + barrier at the end of every stage.
 // MODE 1 -- weights from L2 into registers: 8 MFMA + 4 ds_read_b128 + 2 global 1-KB loads (3 k-steps ahead) per k-step;
 //           waves 0-3 send one window piece in each of the first nine k-steps; one barrier per period.
-template <int MODE>
+template <int MODE, int STRIDED = 0>
 __global__ __launch_bounds__(512) void kmix(int iters, const char* w, unsigned wbytes, float* sink, unsigned long long* cyc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -287,13 +287,15 @@ __global__ __launch_bounds__(512) void kmix(int iters, const char* w, unsigned w
   const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned addr = base + (unsigned)(((lane & 31) * 128) + ((((lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
   auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)wbytes, 0x00020000);
-  unsigned dsrc = (unsigned)(wave * 9 * 1024 + lane * 16);   // DMA source cursor (wraps inside the 2 MB buffer)
+  // DMA source cursor (wraps inside the 2 MB buffer).  STRIDED: a piece is 8 rows of 128 B at a 512-B row stride (a 64-channel
+  // chunk of 256-channel rows, what the real tile fetches) instead of 1 KB in a row
+  unsigned dsrc = STRIDED ? (unsigned)(wave * 9 * 4096 + (lane >> 3) * 512 + (lane & 7) * 16) : (unsigned)(wave * 9 * 1024 + lane * 16);
   unsigned ddst = 0;                                         // DMA destination piece inside [32 KB, 96 KB)
 #define DMA_PIECE()                                                                                    \
   do {                                                                                                 \
     auto lds_ = (__attribute__((address_space(3))) void*)(smem + 32768 + ((ddst + wave) & 63) * 1024);   \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_, 16, dsrc, 0, 0, 0);                             \
-    dsrc = (dsrc + 36 * 1024) & (1u << 20) - 1;                                                        \
+    dsrc = (dsrc + (STRIDED ? 36 * 4096 + 128 : 36 * 1024)) & (1u << 20) - 1;                          \
     ddst += 4;                                                                                         \
   } while (0)
   for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][i]) : "v"(addr + i * 4096));
@@ -386,21 +388,21 @@ __global__ __launch_bounds__(512) void kmix(int iters, const char* w, unsigned w
   if (s == 12345.f) sink[0] = s + smem[40000 + tid];
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
-template <int MODE>
+template <int MODE, int STRIDED = 0>
 void runmix(const char* w, float* sink, unsigned long long* cyc, int blocks) {
   const int iters = 200;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
-  hipFuncSetAttribute((const void*)kmix<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  hipFuncSetAttribute((const void*)kmix<MODE, STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((kmix<MODE>), dim3(blocks), dim3(512), 98304, 0, iters, w, 2u << 20, sink, cyc);
+    hipLaunchKernelGGL((kmix<MODE, STRIDED>), dim3(blocks), dim3(512), 98304, 0, iters, w, 2u << 20, sink, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
   unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
   const double n = iters * 12.0 * 8;
-  printf("mix %s, %d workgroups: %.0f TF/s per 256 CUs (%.1f ticks/MFMA/wave)\n",
+  printf("mix %s%s, %d workgroups: %.0f TF/s per 256 CUs (%.1f ticks/MFMA/wave)\n", STRIDED ? "[pieces of 8 x 128 B rows] " : "",
          MODE ? "weights L2 -> registers, window pieces by DMA" : "weights + window by DMA through LDS", blocks,
          256.0 * 8 * n * 32768.0 / (ms * 1e-3) / 1e12, (double)c / n);
 }
@@ -502,7 +504,7 @@ int main(int argc, char**) {
     hipLaunchKernelGGL((kstep<8, 8, 0, 1>), dim3(256), dim3(512), 65536, 0, 2000, sink, cyc);
   hipDeviceSynchronize();
   for (int rep = 0; rep < 3; ++rep) {
-    runmix4(wbuf, sink, cyc, 256); runmix4(wbuf, sink, cyc, 127);
+    runmix<0, 1>(wbuf, sink, cyc, 256); runmix<0, 1>(wbuf, sink, cyc, 127);
     runmix<0>(wbuf, sink, cyc, 256); runmix<1>(wbuf, sink, cyc, 256); runmix<0>(wbuf, sink, cyc, 127); runmix<1>(wbuf, sink, cyc, 127);
     runk<8, 8, 6, 1>(sink, cyc);
     runb<8, 4, 2, 2>(wbuf, sink, cyc); runb<8, 4, 2, 3>(wbuf, sink, cyc); runb<8, 4, 2, 5>(wbuf, sink, cyc);
