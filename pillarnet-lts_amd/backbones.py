@@ -9,6 +9,7 @@ is one launch of the HIP implicit-GEMM kernel with the norm folded into the epil
 import torch
 import torch.nn as nn
 
+from . import sparse_conv
 from .nn_utils import build_norm_layer
 from .registry import BACKBONES
 from .sparse_conv import (SparseConv2d, SparseModule, SparseReLU, SparseSequential, SubMConv2d,
@@ -111,7 +112,13 @@ class _PillarResNet(nn.Module):
     def forward(self, sp_tensor):
         feats = {}
         x = sp_tensor
+        ahead = None
+        if (sparse_conv.RULES_AHEAD and not self.training and x.features_cap.device.type == "cuda"
+                and x.features_cap.dtype == torch.bfloat16):
+            ahead = sparse_conv.rules_ahead(x, [(getattr(self, f"conv{s}")[0], f"res{s}") for s in (2, 3, 4)])
         for stage in (1, 2, 3, 4):
+            if ahead is not None and stage > 1:
+                x._ahead = ahead[stage - 2]
             x = getattr(self, f"conv{stage}")(x)
             feats[f"conv{stage}"] = x
         if self.DENSE_TAIL:

@@ -124,25 +124,71 @@ def _launch_conv(dt, feats, cin, nbr, stride, num, cap, w, scale, shift, res, re
     _lib.check(rc, "pn_spconv_forward")
 
 
-def _subm_rules(x: SparseConvTensor, key):
+def _subm_rules(x: SparseConvTensor, key, stream=None):
+    """stream: raw handle to launch on instead of the current stream (the tensors are still allocated under the
+    current one -- see rules_ahead)."""
     cached = x.indice_dict.get(key) if key is not None else None
     if cached is not None:
         return cached
-    dev = x.features_cap.device
+    dev = x.indices_cap.device
     cap = x.capacity
     H, W = x.spatial_shape
     nbr = torch.empty((9, cap), dtype=torch.int32, device=dev)
     rc = _lib.lib().pn_spconv_subm_rules(_lib.ptr(x.indices_cap), _lib.ptr(x.num_active), cap,
                                          x.batch_size, H, W, _lib.ptr(x.occ_bits),
-                                         _lib.ptr(x.occ_rank), _lib.ptr(nbr), _lib.current_stream(dev))
+                                         _lib.ptr(x.occ_rank), _lib.ptr(nbr),
+                                         stream if stream is not None else _lib.current_stream(dev))
     _lib.check(rc, "pn_spconv_subm_rules")
     if key is not None:
         x.indice_dict[key] = nbr
     return nbr
 
 
-def _down_rules(x: SparseConvTensor, stride, pad):
-    dev = x.features_cap.device
+# Inference, one frame at a time: the index chain of the strided levels (output sites, occupancy index, rulebooks of
+# levels 2..4 -- a dozen launches of ~6 us that depend on level 1's INDICES only) runs on a side stream beside
+# level 1's convolutions instead of between the levels.  Off by default: it takes 20-30 us off a 1.42 ms frame, a
+# graph with a fork costs the host six times as long to launch, and with several frames in flight the other frame's
+# kernels already fill those gaps.
+RULES_AHEAD = False
+_SIDE_STREAMS = {}
+
+
+class _Ahead:
+    __slots__ = ("event", "out_idx", "out_num", "out_bits", "out_rank", "nbr", "shape", "out_cap", "indice_dict", "keep")
+
+
+def rules_ahead(x: SparseConvTensor, stages):
+    """stages: [(strided conv module, indice_key of the SubM convs behind it)] in network order, starting at `x`.
+    Returns one record per stage; `conv_forward` of that stage's strided conv takes it from `tensor._ahead`, waits for
+    its event and uses its tensors.  Every tensor is allocated under the CURRENT stream and only the launches go to the
+    side stream, so the allocator's stream bookkeeping stays that of an ordinary frame; scratch buffers are kept in the
+    records until the caller drops them (behind the last join)."""
+    dev = x.indices_cap.device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)      # default priority
+    side.wait_stream(main)                                              # the indices come from the reader
+    import ctypes
+    h = ctypes.c_void_p(side.cuda_stream)
+    recs, t = [], x
+    for conv, key in stages:
+        r = _Ahead()
+        r.keep = []
+        r.out_idx, r.out_num, r.out_bits, r.out_rank, r.nbr, r.shape, r.out_cap = _down_rules(
+            t, conv.stride, conv.padding, stream=h, keep=r.keep)
+        t = SparseConvTensor(None, r.out_idx, r.shape, x.batch_size, r.out_num, r.out_bits, r.out_rank)
+        if key is not None:
+            _subm_rules(t, key, stream=h)
+        r.indice_dict = t.indice_dict
+        r.event = torch.cuda.Event()
+        r.event.record(side)
+        recs.append(r)
+    return recs
+
+
+def _down_rules(x: SparseConvTensor, stride, pad, stream=None, keep=None):
+    dev = x.indices_cap.device
     H, W = x.spatial_shape
     Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     B = x.batch_size
@@ -162,8 +208,10 @@ def _down_rules(x: SparseConvTensor, stride, pad):
                                 _lib.ptr(x.occ_bits), _lib.ptr(x.occ_rank), stride, pad, Ho, Wo,
                                 _lib.ptr(out_idx), _lib.ptr(out_num), out_cap, _lib.ptr(out_bits),
                                 _lib.ptr(out_rank), _lib.ptr(nbr), _lib.ptr(scratch), sb,
-                                _lib.current_stream(dev))
+                                stream if stream is not None else _lib.current_stream(dev))
     _lib.check(rc, "pn_spconv_down_rules")
+    if keep is not None:
+        keep.append(scratch)      # launched on another stream: must outlive this call
     return out_idx, out_num, out_bits, out_rank, nbr, (Ho, Wo), out_cap
 
 
@@ -333,11 +381,20 @@ def conv_forward(x: SparseConvTensor, conv: SparseConvolution, bn=None, relu=Fal
                      conv.out_channels, dev)
         return x.replace_feature(out)
     assert residual is None
-    out_idx, out_num, out_bits, out_rank, nbr, shape, out_cap = _down_rules(x, conv.stride, conv.padding)
+    ahead = x.__dict__.pop("_ahead", None)
+    if ahead is not None:          # built beside the previous level's convolutions (rules_ahead)
+        torch.cuda.current_stream(dev).wait_event(ahead.event)
+        out_idx, out_num, out_bits, out_rank, nbr, shape, out_cap = (
+            ahead.out_idx, ahead.out_num, ahead.out_bits, ahead.out_rank, ahead.nbr, ahead.shape, ahead.out_cap)
+    else:
+        out_idx, out_num, out_bits, out_rank, nbr, shape, out_cap = _down_rules(x, conv.stride, conv.padding)
     out = torch.empty((out_cap, conv.out_channels), dtype=feats.dtype, device=dev)
     _launch_conv(dt, feats, conv.in_channels, nbr, out_cap, out_num, out_cap, w, scale, shift, None, relu,
                  out, conv.out_channels, dev)
-    return SparseConvTensor(out, out_idx, shape, x.batch_size, out_num, out_bits, out_rank)
+    y = SparseConvTensor(out, out_idx, shape, x.batch_size, out_num, out_bits, out_rank)
+    if ahead is not None:
+        y.indice_dict = ahead.indice_dict
+    return y
 
 
 class SparseSequential(SparseModule):

@@ -12,7 +12,9 @@ synth.randomize_bn_(model, 1)
 model.to_inference(torch.bfloat16)
 exs = [{"points": [torch.from_numpy(synth.nusc_frame(10, 30000, seed=i)).to(dev)], "metadata": [{"token": i}]} for i in range(4)]
 with torch.no_grad():
-    g = FrameGraphs(model, lanes=1)
+    # ONE_LANE_RULES_AHEAD=0 / 1: the backbone's index chain in line / on the graph's side branch (default: FrameGraphs' own)
+    ra = os.environ.get("ONE_LANE_RULES_AHEAD")
+    g = FrameGraphs(model, lanes=1, rules_ahead=None if ra is None else bool(int(ra)))
     for e in exs:
         g(e)
     fr = next(iter(g.lanes[0].frames.values()))

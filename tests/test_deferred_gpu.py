@@ -175,3 +175,31 @@ def test_frame_graph_degenerate_frames():
             for rep in range(2):                      # once per lane
                 _same(want, graphs(ex))
         assert sorted({k for ln in graphs.lanes for k in ln.frames}) == [(5, (8192,))]
+
+
+def test_index_chain_on_a_side_stream_changes_nothing():
+    """sparse_conv.RULES_AHEAD (FrameGraphs(rules_ahead=True)): the strided levels' index chain runs on a side
+    stream beside level 1 -- eager and captured, replayed with eager work in between, the detections are the same bits"""
+    from pillarnet_lts_amd import FrameGraphs, presets, sparse_conv, synth
+    torch.manual_seed(0)
+    model = presets.build(presets.nusc_pillarnet18())
+    synth.randomize_bn_(model, seed=1)
+    model.to_inference(torch.bfloat16)
+    pts = [torch.from_numpy(synth.nusc_frame(10, 8000, seed=s)).cuda() for s in (21, 22, 23)]
+    on = FrameGraphs(model, bucket=8192, lanes=1, rules_ahead=True)
+    off = FrameGraphs(model, bucket=8192, lanes=1)
+    assert on.rules_ahead and not off.rules_ahead
+    with torch.no_grad():
+        for rep in range(2):
+            for i, f in enumerate(pts):
+                ex = {"points": [f], "metadata": [{"token": i}]}
+                want = model(ex, return_loss=False)
+                assert want[0]["scores"].shape[0] > 0
+                sparse_conv.RULES_AHEAD = True
+                try:
+                    eager_ahead = model(ex, return_loss=False)
+                finally:
+                    sparse_conv.RULES_AHEAD = False
+                _same(want, eager_ahead)
+                _same(want, on(ex))
+                _same(want, off(ex))
