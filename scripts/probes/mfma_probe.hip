@@ -496,6 +496,42 @@ void runmix4(const char* w, float* sink, unsigned long long* cyc, int blocks) {
          blocks, 256.0 * 4 * n * 32768.0 / (ms * 1e-3) / 1e12, (double)c / n);
 }
 
+// fp32 matrix rate: v_mfma_f32_32x32x2_f32 back to back on 4 accumulators, W waves per SIMD, operands in registers
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void kf32(int iters, float* sink, unsigned long long* cyc) {
+  const int tid = threadIdx.x;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  unsigned h = (unsigned)tid * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  float a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = __uint_as_float(((h >> i) & 0x807fffffu) | 0x3b800000u); b[i] = __uint_as_float(((h << i) & 0x807fffffu) | 0x3b000000u); }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+      asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[m & 3]) : "v"(a[m >> 2]), "v"(b[m & 3]));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 4; ++i) s += acc[i][0];
+  if (s == 12345.f) sink[0] = s;
+  if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
+}
+template <int NWAVES>
+void runf32(float* sink, unsigned long long* cyc) {
+  const int iters = 4000 / (NWAVES / 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kf32<NWAVES>), dim3(256), dim3(NWAVES * 64), 0, 0, iters, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double n = (double)iters * 16;
+  printf("fp32 32x32x2 MFMA, %2d waves/CU: %.1f TF/s chip (%.2f ms)\n", NWAVES, 256.0 * NWAVES * n * 4096.0 / (ms * 1e-3) / 1e12, ms);
+}
+
 int main(int argc, char**) {
   float* sink; unsigned long long* cyc;
   hipMalloc(&sink, 4); hipMalloc(&cyc, 8);
@@ -503,6 +539,7 @@ int main(int argc, char**) {
   for (int i = 0; i < 40; ++i)        // the clock takes a while to come up on a cold card
     hipLaunchKernelGGL((kstep<8, 8, 0, 1>), dim3(256), dim3(512), 65536, 0, 2000, sink, cyc);
   hipDeviceSynchronize();
+  runf32<4>(sink, cyc); runf32<8>(sink, cyc); runf32<16>(sink, cyc); runf32<4>(sink, cyc);
   for (int rep = 0; rep < 3; ++rep) {
     runmix<0, 1>(wbuf, sink, cyc, 256); runmix<0, 1>(wbuf, sink, cyc, 127);
     runmix<0>(wbuf, sink, cyc, 256); runmix<1>(wbuf, sink, cyc, 256); runmix<0>(wbuf, sink, cyc, 127); runmix<1>(wbuf, sink, cyc, 127);
