@@ -256,6 +256,11 @@ static int launch_conv(const void* in, const int32_t* nbr, int nbr_stride, const
   return PN_OK;
 }
 
+// spconv_f32.hip
+int pn_spconv_f32_lds(const float* in, int cin, const int32_t* nbr, int nbr_stride, const int32_t* count_dev, int cap,
+                      const float* weight, const float* scale, const float* shift, const float* residual, int relu,
+                      float* out, int cout, hipStream_t stream);
+
 #define PN_CONV_CASE(CI, CO, MT_)                                                                   \
   if (cin == CI && cout == CO) {                                                                    \
     return dtype == PN_DTYPE_BF16                                                                   \
@@ -284,6 +289,11 @@ extern "C" int pn_spconv_forward(int dtype, const void* in, int cin, long long i
                                   residual, cout, relu, out, cout, 0, nullptr, stream_);
     pn_gg_free_order = 0;
     return rc;
+  }
+  if (dtype == PN_DTYPE_F32 && !getenv("PN_SPCONV_F32_V1")) {   // training: LDS-staged fp32 kernel for 64 / 128 / 256 outputs
+    const int rc = pn_spconv_f32_lds((const float*)in, cin, nbr, nbr_stride, count_dev, cap, (const float*)weight, scale,
+                                     shift, (const float*)residual, relu, (float*)out, cout, stream);
+    if (rc != -1) return rc;
   }
   PN_CONV_CASE(32, 32, 4)
   PN_CONV_CASE(32, 64, 4)
