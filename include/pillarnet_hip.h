@@ -403,7 +403,9 @@ int pn_spconv_invert_rules(const int32_t* nbr, int nbr_stride, const int32_t* ou
  * at det3d/models/backbones/base.py:9-36; the reference holds no source for it).  nbr NULL = identity
  * (ntaps must be 1: a plain X^T G product).  cin, cout multiples of 32; x_ld / g_ld = row strides in floats
  * (0: cin / cout); count_dev optional device row count.  Partial sums per site chunk live in `workspace`
- * (pn_spconv_wgrad_workspace_bytes) and are added in a fixed order: results are bit-reproducible. */
+ * (pn_spconv_wgrad_workspace_bytes) and are added in a fixed order: results are bit-reproducible.  Widths that are
+ * multiples of 64 with 16-byte aligned rows (pointers and strides) take the kernel that stages whole rows through
+ * LDS (about twice as fast on the 128- and 256-wide levels); anything else the per-tile kernel. */
 size_t pn_spconv_wgrad_workspace_bytes(int rows, int cin, int cout, int ntaps);
 int pn_spconv_wgrad(const float* x, int cin, int x_ld, const int32_t* nbr, int nbr_stride, int ntaps,
                     const int32_t* count_dev, int rows, const float* grad_out, int cout, int g_ld,

@@ -276,10 +276,9 @@ extern "C" int pn_spconv_wgrad(const float* x, int cin, int x_ld, const int32_t*
   a.x_ld = x_ld; a.g_ld = g_ld; a.nbr_stride = nbr_stride; a.rows = rows; a.cin = cin; a.cout = cout;
   a.ntaps = ntaps; a.chunk_sites = per;
   const size_t n_out = (size_t)ntaps * cout * cin;
-  if (wgrad_lds_shape(cin, cout)) {
-    // (whole rows are fetched 16 bytes per lane)
-    PN_CHECK_ARG(x_ld % 4 == 0 && g_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_out) & 15) == 0,
-                 "pn_spconv_wgrad: rows of %d -> %d layers must be 16-byte aligned (strides %d, %d)", cin, cout, x_ld, g_ld);
+  // (the LDS kernel fetches whole rows 16 bytes per lane; rows that are not 16-byte aligned -- odd strides of a view --
+  // take the per-tile kernel on the same chunks)
+  if (wgrad_lds_shape(cin, cout) && x_ld % 4 == 0 && g_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_out) & 15) == 0) {
     const dim3 grid(chunks, ntaps);
 #define WG_LDS_CASE(NCO_, NCI_)                                                                              \
   if (cout == 64 * NCO_ && cin == 64 * NCI_) {                                                               \

@@ -262,16 +262,20 @@ def test_full_size_sparse_conv_gradient_on_a_sampled_window(cuda):
     np.testing.assert_allclose(got, f.grad.numpy()[inner], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cin,cout,rows,n_in", [(32, 32, 5003, 4000), (64, 32, 777, 900), (32, 64, 1, 5), (64, 64, 20001, 20001),
-                                                (128, 256, 3000, 2500), (256, 256, 4097, 4097)])
-def test_rulebook_weight_gradient_kernel(cuda, cin, cout, rows, n_in):
+@pytest.mark.parametrize("cin,cout,rows,n_in,pad", [(32, 32, 5003, 4000, 32), (64, 32, 777, 900, 32), (32, 64, 1, 5, 32),
+                                                    (64, 64, 20001, 20001, 32), (128, 256, 3000, 2500, 32),
+                                                    (256, 256, 4097, 4097, 32), (128, 128, 9999, 7000, 32),
+                                                    (64, 128, 2049, 2049, 32), (256, 128, 1500, 1500, 32),
+                                                    (128, 128, 5000, 5000, 33), (256, 256, 3001, 3001, 1)])
+def test_rulebook_weight_gradient_kernel(cuda, cin, cout, rows, n_in, pad):
     """pn_spconv_wgrad against the definition in float64: dW[co][tap][ci] = sum_m g[m][co] * x[nbr[tap][m]][ci],
-    missing neighbours (-1) skipped, rows not a multiple of the chunking, row strides wider than the channels;
+    missing neighbours (-1) skipped, rows not a multiple of the chunking, row strides wider than the channels (`pad`
+    odd: rows that are not 16-byte aligned, which the LDS-staged kernel of the wide layers hands to the per-tile one);
     two runs are bit-identical (fixed summation order)."""
     from pillarnet_lts_amd import sparse_conv
     gen = torch.Generator().manual_seed(cin * 1000 + cout + rows)
-    x_full = torch.randn((n_in, cin + 32), generator=gen).to(cuda)
-    g_full = torch.randn((rows, cout + 64), generator=gen).to(cuda)
+    x_full = torch.randn((n_in, cin + pad), generator=gen).to(cuda)
+    g_full = torch.randn((rows, cout + 2 * pad), generator=gen).to(cuda)
     x, g = x_full[:, :cin], g_full[:, :cout]
     nbr = torch.randint(-n_in // 3, n_in, (9, rows + 11), generator=gen).clamp_(min=-1).int().to(cuda)
     got = sparse_conv.rulebook_wgrad(x, nbr, g, rows)
