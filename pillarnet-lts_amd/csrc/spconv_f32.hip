@@ -17,7 +17,11 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-static constexpr int SF_KS = 16;          // input channels per stage
+#ifndef SF_KS_DEF
+#define SF_KS_DEF 16
+#endif
+static constexpr int SF_KS = SF_KS_DEF;   // input channels per stage
+static constexpr int SF_PPR = SF_KS / 4;  // 16-byte pieces per staged row
 static constexpr int SF_LD = SF_KS + 1;   // LDS row stride in floats
 
 struct SpconvF32Args {
@@ -35,8 +39,8 @@ struct SpconvF32Args {
 template <int NCO, int NS>
 __global__ __launch_bounds__(64 * NCO * NS) void spconv_f32_lds_kernel(SpconvF32Args a) {
   constexpr int NT = 64 * NCO * NS, COUT = 64 * NCO, TS = 64 * NS;
-  constexpr int NW = COUT * 4 / NT, NI = TS * 4 / NT;   // 16-byte pieces per thread and stage: weight rows, input rows
-  static_assert(COUT * 4 % NT == 0 && TS * 4 % NT == 0, "a stage's rows must divide over the threads");
+  constexpr int NW = COUT * SF_PPR / NT, NI = TS * SF_PPR / NT;   // 16-byte pieces per thread and stage: weight rows, input rows
+  static_assert(COUT * SF_PPR % NT == 0 && TS * SF_PPR % NT == 0, "a stage's rows must divide over the threads");
   constexpr int BUF = (COUT + TS) * SF_LD;               // floats per stage buffer: weight rows, then site rows
   extern __shared__ __attribute__((aligned(16))) float sf_lds[];   // [2][BUF]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -55,33 +59,33 @@ __global__ __launch_bounds__(64 * NCO * NS) void spconv_f32_lds_kernel(SpconvF32
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // this thread's pieces: weight row (q / 4), input site (q / 4), 16-byte part (q % 4) of the 64-byte slice
+  // this thread's pieces: weight row / input site q / SF_PPR, 16-byte part q % SF_PPR of the row's slice
   f32x4 rw[NW], ri[NI];
   int ix[NI], ixn[NI];                                             // rulebook entries of the current / the next tap
 #define SF_IDX(dst_, tap_)                                                         \
   _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                 \
-    const int m = m0 + (tid + j * NT) / 4;                                         \
+    const int m = m0 + (tid + j * NT) / SF_PPR;                                         \
     dst_[j] = (m < M && (tap_) < 9) ? a.nbr[(size_t)(tap_) * a.nbr_stride + m] : -1; \
   }
 #define SF_LOAD(tap_, kc_)                                                                                     \
   _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                             \
     const int q = tid + j * NT;                                                                                \
-    rw[j] = *reinterpret_cast<const f32x4*>(a.wt + ((size_t)(tap_) * COUT + q / 4) * a.cin + (kc_) * SF_KS + (q % 4) * 4); \
+    rw[j] = *reinterpret_cast<const f32x4*>(a.wt + ((size_t)(tap_) * COUT + q / SF_PPR) * a.cin + (kc_) * SF_KS + (q % SF_PPR) * 4); \
   }                                                                                                            \
   _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                             \
     const int q = tid + j * NT;                                                                                \
-    ri[j] = ix[j] >= 0 ? *reinterpret_cast<const f32x4*>(a.in + (size_t)ix[j] * a.cin + (kc_) * SF_KS + (q % 4) * 4) \
+    ri[j] = ix[j] >= 0 ? *reinterpret_cast<const f32x4*>(a.in + (size_t)ix[j] * a.cin + (kc_) * SF_KS + (q % SF_PPR) * 4) \
                        : f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
   }
 #define SF_STORE(buf_)                                                                       \
   _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                           \
     const int q = tid + j * NT;                                                              \
-    float* d = sf_lds + (buf_) * BUF + (q / 4) * SF_LD + (q % 4) * 4;                        \
+    float* d = sf_lds + (buf_) * BUF + (q / SF_PPR) * SF_LD + (q % SF_PPR) * 4;                        \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = rw[j][e];                           \
   }                                                                                          \
   _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
     const int q = tid + j * NT;                                                              \
-    float* d = sf_lds + (buf_) * BUF + (COUT + q / 4) * SF_LD + (q % 4) * 4;                 \
+    float* d = sf_lds + (buf_) * BUF + (COUT + q / SF_PPR) * SF_LD + (q % SF_PPR) * 4;                 \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = ri[j][e];                           \
   }
   SF_IDX(ix, 0);
