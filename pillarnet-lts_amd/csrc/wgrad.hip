@@ -202,7 +202,10 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* partial,
   }
 }
 
-static constexpr int WG_S = 16;   // sites per staged group of the LDS kernel
+#ifndef WG_S_DEF
+#define WG_S_DEF 16
+#endif
+static constexpr int WG_S = WG_S_DEF;   // sites per staged group of the LDS kernel
 
 // widths the LDS-staged kernel is instantiated for (one wavefront per 64 x 64 tile, at most 16)
 static bool wgrad_lds_shape(int cin, int cout) {
